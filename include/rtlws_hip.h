@@ -1,0 +1,135 @@
+/*
+ * rtlws_hip.h -- the thin extern-"C" HIP shim under the drop-in headers, and
+ * the batch API that the roofline configurations use.
+ *
+ * Everything here is plain C: pointers, sizes, ints.  No HIP or torch types
+ * appear in a signature; a stream is passed as `void*` (a hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream, or NULL for the engine's own).
+ *
+ * Why a batch API exists at all: the reference interface
+ * (src/spectrum.h:11-15) hands over one N-sample frame per call and wants
+ * f64 back in host memory -- 2 KiB in, 8 KiB out per call.  That cannot get
+ * near an HBM roofline, so the same arithmetic is also exposed over
+ * device-resident batches: many frames in, one f32 (or dB, or payload-byte)
+ * spectrum out per K consecutive frames.  spectrum_add_* (spectrum.h) is the
+ * batch-of-one, K=1 case of rtlws_spectra_batch plus a host-side add.
+ *
+ * Reference semantics each entry point reproduces (paths under the
+ * reference tree):
+ *   rtlws_spectra_batch   src/spectrum.c:15-35,47-99 applied K times to a
+ *                         zeroed row (the loop of src/cbb_main.c:50-59), with
+ *                         optional src/cbb_main.c:121-130 dB/clamp epilogue
+ *   rtlws_cic_block_sums  src/resample.c:21-40 (state handled by the caller)
+ *   rtlws_halfband        src/resample.c:53-64
+ */
+#ifndef RTLWS_HIP_H
+#define RTLWS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtlws_engine rtlws_engine;
+
+/* ---- engine / device plumbing ---------------------------------------- */
+
+/* Number of usable HIP devices (0 when none; never negative). */
+int rtlws_device_count(void);
+
+/* One engine per device per user: owns a stream and the twiddle/window
+ * tables.  Returns NULL (and sets rtlws_last_error) if the device cannot be
+ * used -- there is no CPU fallback behind this library. */
+rtlws_engine* rtlws_engine_create(int device);
+void rtlws_engine_destroy(rtlws_engine* e);
+int rtlws_engine_device(const rtlws_engine* e);
+
+/* Last error text of the calling thread ("" when none). */
+const char* rtlws_last_error(void);
+
+void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes);
+void rtlws_dev_free(rtlws_engine* e, void* dptr);
+void* rtlws_pinned_alloc(size_t bytes);
+void rtlws_pinned_free(void* hptr);
+/* Asynchronous on `stream` (NULL: the engine's stream). 0 on success. */
+int rtlws_copy_h2d(rtlws_engine* e, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int rtlws_copy_d2h(rtlws_engine* e, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int rtlws_memset_dev(rtlws_engine* e, void* dst_dev, int value, size_t bytes, void* stream);
+int rtlws_stream_sync(rtlws_engine* e, void* stream);
+
+/* hipEvent timing on a stream, for bench.py's roofline leg. */
+void* rtlws_event_create(void);
+void rtlws_event_destroy(void* ev);
+int rtlws_event_record(void* ev, rtlws_engine* e, void* stream);
+/* Synchronises on `stop`; returns milliseconds, or a negative value. */
+float rtlws_event_elapsed_ms(void* start, void* stop);
+
+/* ---- batched power spectra ------------------------------------------- */
+
+enum rtlws_input {
+    RTLWS_IN_CU8 = 0,       /* cmplx_u8, (x-128)/128      src/spectrum.c:54-58 */
+    RTLWS_IN_CS32 = 1,      /* cmplx_s32, x/128           src/spectrum.c:72-76 */
+    RTLWS_IN_RF32 = 2       /* real f32, (x, 0)           src/spectrum.c:90-94 */
+};
+
+enum rtlws_window {
+    RTLWS_WIN_RECT = 0,     /* reference behaviour: no window */
+    RTLWS_WIN_HANN = 1      /* periodic Hann; build extension */
+};
+
+enum rtlws_output {
+    RTLWS_OUT_POWER_SUM = 0,   /* f32[N]: sum over the K frames, what K calls of
+                                  spectrum_add_* leave in a zeroed buffer */
+    RTLWS_OUT_MEAN_DB = 1,     /* f32[N]: 10*log10(sum / K) */
+    RTLWS_OUT_PAYLOAD_U8 = 2   /* u8[N]: clamp((int)(10*log10(|g*sum/K|)), 0, 255),
+                                  g = 10^(gain_db/10) with C integer division,
+                                  src/cbb_main.c:112,125-128 */
+};
+
+typedef struct rtlws_spectra_desc {
+    int n_fft;        /* 1024, 2048, 4096 (fused kernel) or any N >= 2 (direct DFT kernel) */
+    int k_avg;        /* >= 1 consecutive frames accumulated per output spectrum */
+    int input;        /* enum rtlws_input */
+    int window;       /* enum rtlws_window */
+    int output;       /* enum rtlws_output */
+    int cic_r;        /* 0 or 1: none.  R > 1 (RTLWS_IN_CU8 only): every FFT input
+                         sample is the CIC block sum of R consecutive cmplx_u8,
+                         fed as spectrum_add_cmplx_s32 would (sum/128) */
+    int gain_db;      /* RTLWS_OUT_PAYLOAD_U8 only */
+    int reserved;
+} rtlws_spectra_desc;
+
+/* d_in : nframes * n_fft * max(cic_r,1) input samples, device memory.
+ * d_out: (nframes / k_avg) rows of n_fft outputs, device memory.
+ * nframes must be a multiple of k_avg.  Asynchronous on `stream`.
+ * Returns 0; -1 bad descriptor/size; -3 HIP failure (see rtlws_last_error). */
+int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
+                        long nframes, void* d_out, void* stream);
+
+/* Which kernel a descriptor selects: 1 fused, 2 direct DFT, 0 unsupported. */
+int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* desc);
+
+/* ---- decimators ------------------------------------------------------ */
+
+/* dst[m] = sum_{n<R} (src[m*R+n] - 128) per component, int32, for m < dst_len.
+ * Stateless block sums; resample.h's cic_decimate adds the delay-line
+ * bookkeeping on the host.  Device pointers.  0 / -1 / -3. */
+int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src_cu8, long dst_len,
+                         void* d_dst_cs32, void* stream);
+
+/* y[n] = 0.5*x[2n-5] + sum_{k even} h[k]*x[2n-k] over a buffer that already
+ * has the 10 history samples in front: d_x holds 10 + 2*out_len floats and
+ * x[i] here means d_x[10 + i].  Device pointers.  0 / -1 / -3. */
+int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, void* stream);
+
+/* Bytes of LDS, VGPR count etc. are in DESIGN.md; this returns the grid the
+ * fused kernel would launch for a descriptor and nframes (for tests). */
+int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* desc, long nframes,
+                       int* blocks, int* threads, int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTLWS_HIP_H */

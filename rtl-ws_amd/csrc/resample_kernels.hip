@@ -1,0 +1,126 @@
+// resample_kernels.hip -- the two decimators of reference src/resample.c as
+// stand-alone HIP kernels (the CIC also exists fused into the spectrum kernel).
+//
+// cic_block_sums: reference src/resample.c:21-40 reduces, once the delay-line
+//   bookkeeping is separated out, to dst[m] = sum_{n<R}(src[m*R+n] - 128) per
+//   component in int32 -- exact integer work, one pass over the bytes:
+//   2R bytes read and 8 bytes written per output.  HBM-bound; R = 8 is one
+//   16-byte load and one 8-byte store per thread.
+// halfband: reference src/resample.c:53-64, f32, products and sums in source
+//   order with no contraction so that results are bit-identical to an IEEE
+//   evaluation of the reference's expression.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtlws_internal.h"
+
+namespace rtlws {
+
+__global__ __launch_bounds__(256) void cic8_kernel(const uint4* __restrict__ src,
+                                                   int2* __restrict__ dst, long n)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += stride) {
+        const uint4 s = src[m];
+        unsigned si = 0, sq = 0;
+        si = __builtin_amdgcn_udot4(s.x, 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(s.x, 0x01000100u, sq, false);
+        si = __builtin_amdgcn_udot4(s.y, 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(s.y, 0x01000100u, sq, false);
+        si = __builtin_amdgcn_udot4(s.z, 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(s.z, 0x01000100u, sq, false);
+        si = __builtin_amdgcn_udot4(s.w, 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(s.w, 0x01000100u, sq, false);
+        dst[m] = make_int2((int)si - 8 * 128, (int)sq - 8 * 128);
+    }
+}
+
+// Any R >= 1.  One wavefront owns 64 consecutive outputs = 64*R consecutive
+// input samples, reads them with coalesced 2-byte loads into LDS and then
+// each lane sums its own R samples from LDS (stride R halfwords: odd R is
+// conflict-free, even R costs a few-way conflict on a path that is not the
+// headline).
+__global__ __launch_bounds__(256) void cicr_kernel(const uint16_t* __restrict__ src,
+                                                   int2* __restrict__ dst, long n, int R)
+{
+    extern __shared__ uint16_t stage[];           // 4 waves * 64 * R halfwords
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t* my = stage + (size_t)wave * 64 * R;
+    const long wave_stride = (long)gridDim.x * 4;
+    for (long w = (long)blockIdx.x * 4 + wave; w * 64 < n; w += wave_stride) {
+        const long m0 = w * 64;
+        const long navail = (n - m0 < 64 ? n - m0 : 64) * (long)R;   // samples this wave owns
+        const uint16_t* base = src + m0 * R;
+        for (long i = lane; i < navail; i += 64) my[i] = base[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (m0 + lane < n) {
+            int si = 0, sq = 0;
+            const uint16_t* q = my + (size_t)lane * R;
+            for (int i = 0; i < R; ++i) {
+                const unsigned s = q[i];
+                si += (int)(s & 0xffu);
+                sq += (int)(s >> 8);
+            }
+            dst[m0 + lane] = make_int2(si - 128 * R, sq - 128 * R);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d_dst,
+                                 hipStream_t st)
+{
+    if (dst_len <= 0) return hipSuccess;
+    if (R == 8) {
+        long blocks = (dst_len + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(cic8_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint4*>(d_src), reinterpret_cast<int2*>(d_dst),
+                           dst_len);
+    } else {
+        long blocks = (dst_len + 255) / 256;
+        if (blocks > 256 * 4) blocks = 256 * 4;
+        const size_t lds = sizeof(uint16_t) * 4 * 64 * (size_t)R;
+        if (lds > 64 * 1024) return hipErrorInvalidValue;   // R <= 128
+        hipLaunchKernelGGL(cicr_kernel, dim3((unsigned)blocks), dim3(256), lds, st,
+                           reinterpret_cast<const uint16_t*>(d_src),
+                           reinterpret_cast<int2*>(d_dst), dst_len, R);
+    }
+    return hipGetLastError();
+}
+
+// x points 10 floats into the buffer, so x[-10..-1] is the delay line
+// (reference src/resample.c:57,63: delay[(HALF_BAND_N - 1) + idx]).
+__global__ __launch_bounds__(256) void halfband_kernel(const float* __restrict__ xbuf,
+                                                       float* __restrict__ y, long n)
+{
+    const float h0 = 0.01824f, h2 = -0.11614f, h4 = 0.34790f, h5 = 0.5f;   // src/resample.c:4
+    const float* x = xbuf + 10;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float* c = x + 2 * i;
+        float acc = __fmul_rn(h5, c[-5]);                    // src/resample.c:57
+        acc = __fadd_rn(acc, __fmul_rn(h0, c[0]));           // k = 0   src/resample.c:60-64
+        acc = __fadd_rn(acc, __fmul_rn(h2, c[-2]));          // k = 2
+        acc = __fadd_rn(acc, __fmul_rn(h4, c[-4]));          // k = 4
+        acc = __fadd_rn(acc, __fmul_rn(h4, c[-6]));          // k = 6
+        acc = __fadd_rn(acc, __fmul_rn(h2, c[-8]));          // k = 8
+        acc = __fadd_rn(acc, __fmul_rn(h0, c[-10]));         // k = 10
+        y[i] = acc;
+    }
+}
+
+hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t st)
+{
+    if (out_len <= 0) return hipSuccess;
+    long blocks = (out_len + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(halfband_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_x, d_y, out_len);
+    return hipGetLastError();
+}
+
+}  // namespace rtlws

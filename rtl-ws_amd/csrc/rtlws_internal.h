@@ -1,0 +1,43 @@
+// rtlws_internal.h -- shared between the HIP translation units of librtlws_hip.
+#ifndef RTLWS_INTERNAL_H
+#define RTLWS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtlws {
+
+// Input kinds as the kernels see them (the public enum rtlws_input plus the
+// two CIC-fused variants selected from rtlws_spectra_desc::cic_r).
+enum { IN_CU8 = 0, IN_CS32 = 1, IN_RF32 = 2, IN_CU8_CIC8 = 3, IN_CU8_CICR = 4 };
+enum { OUT_SUM = 0, OUT_DB = 1, OUT_PAYLOAD = 2 };
+
+struct SpectraParams {
+    const void* in;        // device: frames
+    void* out;             // device: rows
+    long ngroups;          // output rows (= nframes / k_avg)
+    int k_avg;
+    int cic_r;             // 1 when unused
+    int n_fft;
+    int out_mode;          // OUT_*
+    const float2* tw1;     // fused: [T][16] W_N^(m1*rev16(s)); direct: [N] W_N^e
+    const float2* tw2;     // fused: [R3][16] scale * W_T^(m2*rev16(s))
+    const float* window;   // [N] or nullptr
+    float db_offset;       // -10*log10(K)
+    float lin_gain;        // gain / K for the payload epilogue
+    float in_scale;        // direct kernel only (fused: folded into tw2)
+};
+
+// LDS the fused kernel needs, in float2 units: 16 padded rows + one spare slot.
+constexpr int fused_lds_f2(int n_fft) { return 16 * (n_fft / 16 + n_fft / 256) + 2; }
+
+hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);
+hipError_t launch_spectra_fused_2048(const SpectraParams&, int in_kind, int blocks, hipStream_t);
+hipError_t launch_spectra_fused_4096(const SpectraParams&, int in_kind, int blocks, hipStream_t);
+hipError_t launch_spectra_direct(const SpectraParams&, int in_kind, hipStream_t);
+
+hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d_dst, hipStream_t);
+hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t);
+
+}  // namespace rtlws
+#endif

@@ -1,0 +1,392 @@
+// shim.hip -- the extern-"C" layer declared in include/rtlws_hip.h.
+//
+// Host C code (rtl-ws_amd/host/*.c) and the Python test/bench plumbing reach
+// the kernels only through these functions.  The twiddle tables are computed
+// here in f64 and rounded once to f32.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rtlws_hip.h"
+#include "rtlws_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char* what, hipError_t e)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    g_err = buf;
+}
+
+#define HIP_TRY(expr, ret)                      \
+    do {                                        \
+        hipError_t _e = (expr);                 \
+        if (_e != hipSuccess) {                 \
+            set_err(#expr, _e);                 \
+            return ret;                         \
+        }                                       \
+    } while (0)
+
+struct Tables {
+    float2* tw1 = nullptr;
+    float2* tw2_unit = nullptr;     // input scale 1      (real f32)
+    float2* tw2_128 = nullptr;      // input scale 1/128  (u8, s32, CIC)
+    float* hann = nullptr;
+};
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+
+}  // namespace
+
+struct rtlws_engine {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::map<int, Tables> tables;   // by n_fft (fused) or -n_fft (direct)
+};
+
+namespace {
+
+int rev16h(int s) { return 4 * (s & 3) + (s >> 2); }
+
+bool is_fused_n(int n) { return n == 1024 || n == 2048 || n == 4096; }
+
+// Build (once per engine and N) the per-thread twiddle tables of the fused
+// kernel: tw1[t][s] = W_N^(t * rev16(s)), tw2[m2][s] = scale * W_T^(m2 * rev16(s)).
+int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int key = fused ? n_fft : -n_fft;
+    auto it = e->tables.find(key);
+    if (it != e->tables.end()) { *out = it->second; return 0; }
+    Tables tb;
+    HIP_TRY(hipSetDevice(e->device), -3);
+    if (fused) {
+        const int T = n_fft / 16, R3 = n_fft / 256;
+        std::vector<float2> h1((size_t)T * 16), h2u((size_t)R3 * 16), h2s((size_t)R3 * 16);
+        for (int t = 0; t < T; ++t)
+            for (int s = 0; s < 16; ++s) {
+                const long ex = ((long)t * rev16h(s)) % n_fft;
+                const double a = -kTwoPi * (double)ex / (double)n_fft;
+                h1[(size_t)t * 16 + s] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        for (int m = 0; m < R3; ++m)
+            for (int s = 0; s < 16; ++s) {
+                const long ex = ((long)m * rev16h(s)) % T;
+                const double a = -kTwoPi * (double)ex / (double)T;
+                const double c = std::cos(a), sn = std::sin(a);
+                h2u[(size_t)m * 16 + s] = make_float2((float)c, (float)sn);
+                h2s[(size_t)m * 16 + s] = make_float2((float)c * 0.0078125f, (float)sn * 0.0078125f);
+            }
+        HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMalloc(&tb.tw2_unit, h2u.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMalloc(&tb.tw2_128, h2s.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMemcpy(tb.tw1, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        HIP_TRY(hipMemcpy(tb.tw2_unit, h2u.data(), h2u.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        HIP_TRY(hipMemcpy(tb.tw2_128, h2s.data(), h2s.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+    } else {
+        std::vector<float2> h1((size_t)n_fft);
+        for (int k = 0; k < n_fft; ++k) {
+            const double a = -kTwoPi * (double)k / (double)n_fft;
+            h1[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMemcpy(tb.tw1, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+    }
+    {
+        std::vector<float> hw((size_t)n_fft);
+        for (int n = 0; n < n_fft; ++n)
+            hw[n] = (float)(0.5 - 0.5 * std::cos(kTwoPi * (double)n / (double)n_fft));
+        HIP_TRY(hipMalloc(&tb.hann, hw.size() * sizeof(float)), -3);
+        HIP_TRY(hipMemcpy(tb.hann, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice), -3);
+    }
+    e->tables[key] = tb;
+    *out = tb;
+    return 0;
+}
+
+hipStream_t pick_stream(rtlws_engine* e, void* stream)
+{
+    return stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+}
+
+bool desc_ok(const rtlws_spectra_desc* d)
+{
+    if (!d) return false;
+    if (d->n_fft < 2 || d->k_avg < 1) return false;
+    if (d->input < RTLWS_IN_CU8 || d->input > RTLWS_IN_RF32) return false;
+    if (d->window != RTLWS_WIN_RECT && d->window != RTLWS_WIN_HANN) return false;
+    if (d->output < RTLWS_OUT_POWER_SUM || d->output > RTLWS_OUT_PAYLOAD_U8) return false;
+    if (d->cic_r < 0) return false;
+    if (d->cic_r > 1 && d->input != RTLWS_IN_CU8) return false;
+    if (!is_fused_n(d->n_fft) && d->n_fft > 8192) return false;   // direct kernel: frame in <=64 KiB LDS
+    return true;
+}
+
+int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups)
+{
+    // 12 wavefronts per CU (3 per SIMD at <=168 VGPRs; LDS 12 x 8.5 KiB):
+    // 12, 6 or 3 workgroups per CU.  Persistent: each strides over the rows.
+    const int per_cu = 12 / (n_fft / 1024);
+    long blocks = (long)e->cu_count * per_cu;
+    if (blocks > ngroups) blocks = ngroups;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtlws_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+rtlws_engine* rtlws_engine_create(int device)
+{
+    g_err.clear();
+    int n = rtlws_device_count();
+    if (device < 0 || device >= n) {
+        g_err = "rtlws_engine_create: no such HIP device (there is no CPU fallback)";
+        return nullptr;
+    }
+    HIP_TRY(hipSetDevice(device), nullptr);
+    rtlws_engine* e = new rtlws_engine;
+    e->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        e->cu_count = prop.multiProcessorCount;
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        set_err("hipStreamCreate", err);
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+void rtlws_engine_destroy(rtlws_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->tables) {
+        (void)hipFree(kv.second.tw1);
+        (void)hipFree(kv.second.tw2_unit);
+        (void)hipFree(kv.second.tw2_128);
+        (void)hipFree(kv.second.hann);
+    }
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int rtlws_engine_device(const rtlws_engine* e) { return e ? e->device : -1; }
+
+const char* rtlws_last_error(void) { return g_err.c_str(); }
+
+void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes)
+{
+    void* p = nullptr;
+    HIP_TRY(hipSetDevice(e->device), nullptr);
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 1), nullptr);
+    return p;
+}
+
+void rtlws_dev_free(rtlws_engine* e, void* dptr)
+{
+    if (!dptr) return;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(dptr);
+}
+
+void* rtlws_pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), nullptr);
+    return p;
+}
+
+void rtlws_pinned_free(void* hptr)
+{
+    if (hptr) (void)hipHostFree(hptr);
+}
+
+int rtlws_copy_h2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
+{
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick_stream(e, stream)), -3);
+    return 0;
+}
+
+int rtlws_copy_d2h(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
+{
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick_stream(e, stream)), -3);
+    return 0;
+}
+
+int rtlws_memset_dev(rtlws_engine* e, void* dst, int value, size_t bytes, void* stream)
+{
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, pick_stream(e, stream)), -3);
+    return 0;
+}
+
+int rtlws_stream_sync(rtlws_engine* e, void* stream)
+{
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipStreamSynchronize(pick_stream(e, stream)), -3);
+    return 0;
+}
+
+void* rtlws_event_create(void)
+{
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreate(&ev), nullptr);
+    return ev;
+}
+
+void rtlws_event_destroy(void* ev)
+{
+    if (ev) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev));
+}
+
+int rtlws_event_record(void* ev, rtlws_engine* e, void* stream)
+{
+    HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), pick_stream(e, stream)), -3);
+    return 0;
+}
+
+float rtlws_event_elapsed_ms(void* start, void* stop)
+{
+    float ms = -1.0f;
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)), -1.0f);
+    HIP_TRY(hipEventElapsedTime(&ms, reinterpret_cast<hipEvent_t>(start),
+                                reinterpret_cast<hipEvent_t>(stop)), -1.0f);
+    return ms;
+}
+
+int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* d)
+{
+    if (!desc_ok(d)) return 0;
+    return is_fused_n(d->n_fft) ? 1 : 2;
+}
+
+int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframes, int* blocks,
+                       int* threads, int* lds_bytes)
+{
+    if (!e || !desc_ok(d) || nframes < 0 || nframes % d->k_avg) return -1;
+    const long ngroups = nframes / d->k_avg;
+    if (is_fused_n(d->n_fft)) {
+        if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups);
+        if (threads) *threads = d->n_fft / 16;
+        if (lds_bytes) *lds_bytes = (int)(sizeof(float2) * rtlws::fused_lds_f2(d->n_fft));
+    } else {
+        if (blocks) *blocks = (int)ngroups;
+        if (threads) *threads = 256;
+        if (lds_bytes) *lds_bytes = (int)(sizeof(float2) * d->n_fft);
+    }
+    return 0;
+}
+
+int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void* d_in,
+                        long nframes, void* d_out, void* stream)
+{
+    g_err.clear();
+    if (!e || !desc_ok(d) || !d_in || !d_out || nframes < 0 || nframes % d->k_avg) {
+        g_err = "rtlws_spectra_batch: bad descriptor, pointer or frame count";
+        return -1;
+    }
+    if (nframes == 0) return 0;
+    const bool fused = is_fused_n(d->n_fft);
+    Tables tb;
+    if (get_tables(e, d->n_fft, fused, &tb) != 0) return -3;
+
+    rtlws::SpectraParams p;
+    std::memset(&p, 0, sizeof p);
+    p.in = d_in;
+    p.out = d_out;
+    p.ngroups = nframes / d->k_avg;
+    p.k_avg = d->k_avg;
+    p.cic_r = d->cic_r > 1 ? d->cic_r : 1;
+    p.n_fft = d->n_fft;
+    p.out_mode = d->output;
+    p.tw1 = tb.tw1;
+    const bool scaled = (d->input != RTLWS_IN_RF32);
+    p.tw2 = scaled ? tb.tw2_128 : tb.tw2_unit;
+    p.in_scale = scaled ? 0.0078125f : 1.0f;
+    p.window = (d->window == RTLWS_WIN_HANN) ? tb.hann : nullptr;
+    p.db_offset = (float)(-10.0 * std::log10((double)d->k_avg));
+    // reference src/cbb_main.c:112: pow(10, gain_db/10) with C integer division
+    p.lin_gain = (float)(std::pow(10.0, (double)(d->gain_db / 10)) / (double)d->k_avg);
+
+    int in_kind = d->input;
+    if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::IN_CU8_CICR;
+
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipStream_t st = pick_stream(e, stream);
+    hipError_t err;
+    if (fused) {
+        const int blocks = fused_blocks(e, d->n_fft, p.ngroups);
+        switch (d->n_fft) {
+        case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
+        case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;
+        default: err = rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st); break;
+        }
+    } else {
+        if (in_kind == rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8_CICR;
+        err = rtlws::launch_spectra_direct(p, in_kind, st);
+    }
+    if (err != hipSuccess) {
+        set_err("spectra kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len, void* d_dst,
+                         void* stream)
+{
+    g_err.clear();
+    if (!e || R < 1 || R > 128 || dst_len < 0 || (dst_len > 0 && (!d_src || !d_dst))) {
+        g_err = "rtlws_cic_block_sums: bad argument (1 <= R <= 128)";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_cic_block_sums(R, d_src, dst_len, d_dst, pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("cic kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, void* stream)
+{
+    g_err.clear();
+    if (!e || out_len < 0 || (out_len > 0 && (!d_x || !d_y))) {
+        g_err = "rtlws_halfband: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_halfband(d_x, d_y, out_len, pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("halfband kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+}  // extern "C"

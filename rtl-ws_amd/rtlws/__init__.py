@@ -1,0 +1,372 @@
+"""ctypes front end of the product libraries (rtl-ws_amd/lib/*.so).
+
+This is plumbing for tests/, bench.py and __graft_entry__: it loads the C-ABI
+declared in include/*.h and nothing else.  There is no CPU implementation
+behind it -- if the libraries are missing or no HIP device is usable, calls
+fail loudly.
+
+  Engine ............ include/rtlws_hip.h (batch API on device buffers)
+  Spectrum .......... include/spectrum.h      (reference src/spectrum.h:7-17)
+  cic_decimate ...... include/resample.h      (reference src/resample.h:14)
+  halfband_decimate . include/resample.h      (reference src/resample.h:17)
+  RfDecimator ....... include/rf_decimator.h  (reference src/rf_decimator.h:6-21)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)                       # rtl-ws_amd/
+LIB_DIR = os.path.join(ROOT, "lib")
+HIP_LIB = os.path.join(LIB_DIR, "librtlws_hip.so")
+AMD_LIB = os.path.join(LIB_DIR, "librtlws_amd.so")
+
+IN_CU8, IN_CS32, IN_RF32 = 0, 1, 2
+WIN_RECT, WIN_HANN = 0, 1
+OUT_POWER_SUM, OUT_MEAN_DB, OUT_PAYLOAD_U8 = 0, 1, 2
+
+_INPUTS = {"cu8": IN_CU8, "cs32": IN_CS32, "rf32": IN_RF32}
+_WINDOWS = {"rect": WIN_RECT, "hann": WIN_HANN, None: WIN_RECT}
+_OUTPUTS = {"power_sum": OUT_POWER_SUM, "mean_db": OUT_MEAN_DB, "payload_u8": OUT_PAYLOAD_U8}
+
+
+def build(jobs=8):
+    """Compile every HIP/C source for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", ROOT, "-j%d" % jobs], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("rtl-ws_amd build failed:\n" + out.stdout[-4000:] + out.stderr[-4000:])
+
+
+class SpectraDesc(C.Structure):
+    _fields_ = [("n_fft", C.c_int), ("k_avg", C.c_int), ("input", C.c_int), ("window", C.c_int),
+                ("output", C.c_int), ("cic_r", C.c_int), ("gain_db", C.c_int), ("reserved", C.c_int)]
+
+
+class CmplxS32(C.Structure):
+    _fields_ = [("re", C.c_int32), ("im", C.c_int32)]
+
+
+class CicDelayLine(C.Structure):
+    _fields_ = [("integrator_prev_out", CmplxS32), ("comb_prev_in", CmplxS32)]
+
+
+# every symbol include/*.h declares, by library (tests check the exports)
+HIP_SYMBOLS = [
+    "rtlws_device_count", "rtlws_engine_create", "rtlws_engine_destroy", "rtlws_engine_device",
+    "rtlws_last_error", "rtlws_dev_alloc", "rtlws_dev_free", "rtlws_pinned_alloc",
+    "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
+    "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
+    "rtlws_event_elapsed_ms", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
+    "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid",
+]
+AMD_SYMBOLS = [
+    "spectrum_alloc", "spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32",
+    "spectrum_free", "cic_decimate", "halfband_decimate", "rf_decimator_alloc",
+    "rf_decimator_add_callback", "rf_decimator_set_parameters", "rf_decimator_decimate_cmplx_u8",
+    "rf_decimator_remove_callbacks", "rf_decimator_free",
+]
+
+_hip = None
+_amd = None
+
+
+def _need(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C rtl-ws_amd). There is no CPU fallback." % path)
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        _need(HIP_LIB)
+        L = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
+        vp, i, l, sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+        L.rtlws_device_count.restype = i
+        L.rtlws_engine_create.argtypes = [i]
+        L.rtlws_engine_create.restype = vp
+        L.rtlws_engine_destroy.argtypes = [vp]
+        L.rtlws_engine_device.argtypes = [vp]
+        L.rtlws_last_error.restype = C.c_char_p
+        L.rtlws_dev_alloc.argtypes = [vp, sz]
+        L.rtlws_dev_alloc.restype = vp
+        L.rtlws_dev_free.argtypes = [vp, vp]
+        L.rtlws_pinned_alloc.argtypes = [sz]
+        L.rtlws_pinned_alloc.restype = vp
+        L.rtlws_pinned_free.argtypes = [vp]
+        L.rtlws_copy_h2d.argtypes = [vp, vp, vp, sz, vp]
+        L.rtlws_copy_d2h.argtypes = [vp, vp, vp, sz, vp]
+        L.rtlws_memset_dev.argtypes = [vp, vp, i, sz, vp]
+        L.rtlws_stream_sync.argtypes = [vp, vp]
+        L.rtlws_event_create.restype = vp
+        L.rtlws_event_destroy.argtypes = [vp]
+        L.rtlws_event_record.argtypes = [vp, vp, vp]
+        L.rtlws_event_elapsed_ms.argtypes = [vp, vp]
+        L.rtlws_event_elapsed_ms.restype = C.c_float
+        L.rtlws_spectra_batch.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
+        L.rtlws_spectra_kernel_kind.argtypes = [C.POINTER(SpectraDesc)]
+        L.rtlws_cic_block_sums.argtypes = [vp, i, vp, l, vp, vp]
+        L.rtlws_halfband.argtypes = [vp, vp, vp, l, vp]
+        L.rtlws_spectra_grid.argtypes = [vp, C.POINTER(SpectraDesc), l, C.POINTER(i),
+                                         C.POINTER(i), C.POINTER(i)]
+        _hip = L
+    return _hip
+
+
+def amd_lib():
+    global _amd
+    if _amd is None:
+        hip_lib()
+        _need(AMD_LIB)
+        L = C.CDLL(AMD_LIB)
+        vp, i = C.c_void_p, C.c_int
+        L.spectrum_alloc.argtypes = [i]
+        L.spectrum_alloc.restype = vp
+        for n in ("spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32"):
+            f = getattr(L, n)
+            f.argtypes = [vp, vp, vp, i]
+            f.restype = i
+        L.spectrum_free.argtypes = [vp]
+        L.cic_decimate.argtypes = [i, vp, i, vp, i, C.POINTER(CicDelayLine)]
+        L.cic_decimate.restype = i
+        L.halfband_decimate.argtypes = [vp, vp, i, vp]
+        L.halfband_decimate.restype = None
+        L.rf_decimator_alloc.restype = vp
+        L.rf_decimator_add_callback.argtypes = [vp, vp]
+        L.rf_decimator_set_parameters.argtypes = [vp, C.c_double, i]
+        L.rf_decimator_set_parameters.restype = i
+        L.rf_decimator_decimate_cmplx_u8.argtypes = [vp, vp, i]
+        L.rf_decimator_decimate_cmplx_u8.restype = i
+        L.rf_decimator_remove_callbacks.argtypes = [vp]
+        L.rf_decimator_free.argtypes = [vp]
+        _amd = L
+    return _amd
+
+
+def last_error():
+    return hip_lib().rtlws_last_error().decode()
+
+
+def device_count():
+    return hip_lib().rtlws_device_count()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_desc(n_fft, k_avg=1, input="cu8", window="rect", output="power_sum", cic_r=0, gain_db=0):
+    return SpectraDesc(int(n_fft), int(k_avg), _INPUTS.get(input, input), _WINDOWS.get(window, window),
+                       _OUTPUTS.get(output, output), int(cic_r), int(gain_db), 0)
+
+
+class DevBuf:
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, int(nbytes)
+        self.ptr = hip_lib().rtlws_dev_alloc(eng.h, self.nbytes)
+        if not self.ptr:
+            raise RuntimeError("rtlws_dev_alloc(%d) failed: %s" % (nbytes, last_error()))
+
+    def free(self):
+        if self.ptr:
+            hip_lib().rtlws_dev_free(self.eng.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One engine per device (include/rtlws_hip.h). Fails loudly without a GPU."""
+
+    def __init__(self, device=0):
+        self.h = hip_lib().rtlws_engine_create(int(device))
+        if not self.h:
+            raise RuntimeError("rtlws_engine_create(%d) failed: %s" % (device, last_error()))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            hip_lib().rtlws_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ----------------------------------------------------------
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr, stream=None):
+        arr = np.ascontiguousarray(arr)
+        buf = DevBuf(self, arr.nbytes)
+        self._chk(hip_lib().rtlws_copy_h2d(self.h, buf.ptr, _p(arr), arr.nbytes, stream), "h2d")
+        self.sync(stream)
+        return buf
+
+    def download(self, buf, dtype, shape, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= buf.nbytes
+        self._chk(hip_lib().rtlws_copy_d2h(self.h, _p(out), buf.ptr, out.nbytes, stream), "d2h")
+        self.sync(stream)
+        return out
+
+    def sync(self, stream=None):
+        self._chk(hip_lib().rtlws_stream_sync(self.h, stream), "sync")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, last_error()))
+
+    # -- kernels (device pointers: ints or DevBuf) --------------------------
+    @staticmethod
+    def _ptr(x):
+        return x.ptr if isinstance(x, DevBuf) else int(x)
+
+    def spectra_batch(self, desc, d_in, nframes, d_out, stream=None, check=True):
+        rc = hip_lib().rtlws_spectra_batch(self.h, C.byref(desc), self._ptr(d_in), int(nframes),
+                                           self._ptr(d_out), stream)
+        if check:
+            self._chk(rc, "rtlws_spectra_batch")
+        return rc
+
+    def cic_block_sums(self, R, d_src, dst_len, d_dst, stream=None, check=True):
+        rc = hip_lib().rtlws_cic_block_sums(self.h, int(R), self._ptr(d_src), int(dst_len),
+                                            self._ptr(d_dst), stream)
+        if check:
+            self._chk(rc, "rtlws_cic_block_sums")
+        return rc
+
+    def halfband(self, d_x, d_y, out_len, stream=None):
+        self._chk(hip_lib().rtlws_halfband(self.h, self._ptr(d_x), self._ptr(d_y), int(out_len),
+                                           stream), "rtlws_halfband")
+
+    def grid(self, desc, nframes):
+        b, t, l = C.c_int(), C.c_int(), C.c_int()
+        rc = hip_lib().rtlws_spectra_grid(self.h, C.byref(desc), int(nframes), C.byref(b),
+                                          C.byref(t), C.byref(l))
+        return rc, b.value, t.value, l.value
+
+    # -- convenience: host arrays in, host arrays out ------------------------
+    def spectra(self, data, n_fft, k_avg=1, input="cu8", window="rect", output="power_sum",
+                cic_r=0, gain_db=0):
+        desc = make_desc(n_fft, k_avg, input, window, output, cic_r, gain_db)
+        data = np.ascontiguousarray(data)
+        per_sample = {"cu8": 2, "cs32": 8, "rf32": 4}[input] * max(int(cic_r), 1)
+        nframes = data.nbytes // (per_sample * n_fft)
+        assert nframes * per_sample * n_fft == data.nbytes
+        rows = nframes // k_avg
+        out_dtype = np.uint8 if output == "payload_u8" else np.float32
+        d_in = self.upload(data)
+        d_out = self.alloc(rows * n_fft * np.dtype(out_dtype).itemsize)
+        self.spectra_batch(desc, d_in, nframes, d_out)
+        res = self.download(d_out, out_dtype, (rows, n_fft))
+        d_in.free()
+        d_out.free()
+        return res
+
+
+# ---- drop-in API (librtlws_amd.so) -----------------------------------------
+
+class Spectrum:
+    """struct spectrum* of include/spectrum.h."""
+
+    def __init__(self, N):
+        self.N = N
+        self.h = amd_lib().spectrum_alloc(int(N))
+        if not self.h:
+            raise RuntimeError("spectrum_alloc(%d) returned NULL: %s" % (N, last_error()))
+
+    def add_cmplx_u8(self, src, ps, length=None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        return amd_lib().spectrum_add_cmplx_u8(self.h, _p(src), _p(ps),
+                                               self.N if length is None else length)
+
+    def add_cmplx_s32(self, src, ps, length=None):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        return amd_lib().spectrum_add_cmplx_s32(self.h, _p(src), _p(ps),
+                                                self.N if length is None else length)
+
+    def add_real_f32(self, src, ps, length=None):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        return amd_lib().spectrum_add_real_f32(self.h, _p(src), _p(ps),
+                                               self.N if length is None else length)
+
+    def free(self):
+        if self.h:
+            amd_lib().spectrum_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def cic_decimate(R, src, state=None, dst_len=None):
+    """include/resample.h cic_decimate. Returns (rc, dst int32[dst_len,2], state int32[4])."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).reshape(-1, 2)
+    src_len = src.shape[0]
+    if dst_len is None:
+        dst_len = src_len // R if R > 0 else 0
+    dst = np.zeros((max(dst_len, 0), 2), dtype=np.int32)
+    st = [0, 0, 0, 0] if state is None else [int(x) for x in state]
+    d = CicDelayLine(CmplxS32(st[0], st[1]), CmplxS32(st[2], st[3]))
+    rc = amd_lib().cic_decimate(int(R), _p(src), src_len, _p(dst), dst_len, C.byref(d))
+    out_state = np.array([d.integrator_prev_out.re, d.integrator_prev_out.im,
+                          d.comb_prev_in.re, d.comb_prev_in.im], dtype=np.int32)
+    return rc, dst, out_state
+
+
+def halfband_decimate(inp, delay):
+    inp = np.ascontiguousarray(inp, dtype=np.float32)
+    assert delay.dtype == np.float32 and delay.size == 10
+    out = np.empty(inp.size // 2, dtype=np.float32)
+    amd_lib().halfband_decimate(_p(inp), _p(out), out.size, _p(delay))
+    return out
+
+
+_RF_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+
+class RfDecimator:
+    """struct rf_decimator* of include/rf_decimator.h; callback blocks are collected."""
+
+    def __init__(self):
+        self.h = amd_lib().rf_decimator_alloc()
+        self.blocks = []
+
+        def _cb(ptr, n):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(n, 2))
+            self.blocks.append(a.copy())
+
+        self._cb = _RF_CB(_cb)
+        amd_lib().rf_decimator_add_callback(self.h, C.cast(self._cb, C.c_void_p))
+
+    def set_parameters(self, sample_rate, down_factor):
+        return amd_lib().rf_decimator_set_parameters(self.h, float(sample_rate), int(down_factor))
+
+    def decimate(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1, 2)
+        return amd_lib().rf_decimator_decimate_cmplx_u8(self.h, _p(iq), iq.shape[0])
+
+    def free(self):
+        if self.h:
+            amd_lib().rf_decimator_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

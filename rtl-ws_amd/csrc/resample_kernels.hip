@@ -98,6 +98,8 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
 __global__ __launch_bounds__(256) void halfband_kernel(const float* __restrict__ xbuf,
                                                        float* __restrict__ y, long n)
 {
+    // This file is compiled with -ffp-contract=off (Makefile): mul then add, never
+    // fma, for bit parity with an IEEE evaluation of the C expression.
     const float h0 = 0.01824f, h2 = -0.11614f, h4 = 0.34790f, h5 = 0.5f;   // src/resample.c:4
     const float* x = xbuf + 10;
     const long stride = (long)gridDim.x * blockDim.x;

@@ -187,7 +187,8 @@ def main():
             }
 
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            # the GPU box gives one GPU's job a 16-CPU share whatever nproc says
+            cores = min(len(os.sched_getaffinity(0)), 16)
             sample = min(frames, 16384 if n_fft <= 1024 else 4096)
             sample -= sample % k_avg
             host = ins[0][:sample].cpu().numpy()

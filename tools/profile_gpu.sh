@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: kernel-trace stats plus
+# separate PMC passes, all over the same bench command.  Output under
+# gpurun_out/prof_<tag>/; copy the summaries you want judged into profiles/.
+set -e
+TAG=${1:-r01}
+WORKLOAD=${2:-batched_1024pt_64k_frames}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WORKLOAD"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $CMD > /dev/null 2> $OUT/pmc_sq2.err
+find $OUT -name "*.csv" | head -50

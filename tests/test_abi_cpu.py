@@ -1,0 +1,87 @@
+"""CPU suite: the C-ABI libraries load and export every symbol include/*.h
+declares (no compute calls: there is no GPU here), and fail loudly without one."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(INCLUDE, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    txt = re.sub(r'extern\s+"C"\s*\{', "", txt)            # keep what the linkage block holds
+    txt = re.sub(r"^\s*#.*$", "", txt, flags=re.M)
+    for _ in range(3):                                   # drop struct/enum bodies
+        txt = re.sub(r"\{[^{}]*\}", "", txt)
+    txt = re.sub(r"typedef[^;]*;", "", txt)              # function-pointer typedefs
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{}]*\)\s*;", txt)
+    return [n for n in names if n not in ("defined", "sizeof")]
+
+
+def test_every_declared_symbol_is_exported(built):
+    hip = ctypes.CDLL(built.HIP_LIB, mode=ctypes.RTLD_GLOBAL)
+    amd = ctypes.CDLL(built.AMD_LIB)
+    declared_hip = _declared_functions("rtlws_hip.h")
+    assert len(declared_hip) >= 20
+    for name in declared_hip:
+        assert hasattr(hip, name), "librtlws_hip.so lacks " + name
+    declared_amd = []
+    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "cbb_main.h"):
+        if os.path.exists(os.path.join(INCLUDE, h)):
+            fns = _declared_functions(h)
+            assert fns, h
+            declared_amd += fns
+    for name in declared_amd:
+        assert hasattr(amd, name), "librtlws_amd.so lacks " + name
+    # the binding's own lists agree with the headers
+    assert set(built.HIP_SYMBOLS) == set(declared_hip)
+    assert set(built.AMD_SYMBOLS) <= set(declared_amd)
+
+
+def test_abi_struct_layouts(built):
+    assert ctypes.sizeof(built.SpectraDesc) == 32
+    assert ctypes.sizeof(built.CicDelayLine) == 16        # two cmplx_s32, src/resample.h:8-12
+    assert ctypes.sizeof(built.CmplxS32) == 8             # src/common_sp.h:13-20
+
+
+def test_descriptor_validation_needs_no_gpu(built):
+    L = built.hip_lib()
+    kind = lambda **kw: L.rtlws_spectra_kernel_kind(ctypes.byref(built.make_desc(**kw)))
+    assert kind(n_fft=1024) == 1 and kind(n_fft=2048) == 1 and kind(n_fft=4096) == 1
+    assert kind(n_fft=1000) == 2 and kind(n_fft=512) == 2
+    assert kind(n_fft=1) == 0 and kind(n_fft=1024, k_avg=0) == 0
+    assert kind(n_fft=1024, input="cs32", cic_r=8) == 0
+    assert kind(n_fft=100000) == 0
+
+
+def test_no_gpu_fails_loudly(built):
+    """Without a HIP device the product path must refuse, never fall back."""
+    if built.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        built.Engine(0)
+    with pytest.raises(RuntimeError):
+        built.Spectrum(1024)
+    rc, _, _ = built.cic_decimate(8, np.zeros((64, 2), dtype=np.uint8))
+    assert rc == -3
+
+
+def test_product_never_touches_the_oracle():
+    """No file under rtl-ws_amd/ or include/ mentions the oracle library."""
+    bad = []
+    for base in ("rtl-ws_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp or dp.endswith("lib"):
+                continue
+            for f in fn:
+                if f.endswith((".c", ".h", ".hip", ".py", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"pyoracle|rtlws_oracle|orc_[a-z]", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -21,7 +21,7 @@ struct SpectraParams {
     int n_fft;
     int out_mode;          // OUT_*
     const float2* tw1;     // fused: [T][16] W_N^(m1*rev16(s)); direct: [N] W_N^e
-    const float2* tw2;     // fused: [R3][16] scale * W_T^(m2*rev16(s))
+    const float2* tw2;     // fused: [16][R3] scale * W_T^(m*q2)
     const float* window;   // [N] or nullptr
     float db_offset;       // -10*log10(K)
     float lin_gain;        // gain / K for the payload epilogue

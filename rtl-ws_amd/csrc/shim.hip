@@ -62,7 +62,7 @@ int rev16h(int s) { return 4 * (s & 3) + (s >> 2); }
 bool is_fused_n(int n) { return n == 1024 || n == 2048 || n == 4096; }
 
 // Build (once per engine and N) the per-thread twiddle tables of the fused
-// kernel: tw1[t][s] = W_N^(t * rev16(s)), tw2[m2][s] = scale * W_T^(m2 * rev16(s)).
+// kernel: tw1[t][s] = W_N^(t * rev16(s)), tw2[q2][m] = scale * W_T^(m * q2).
 int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
 {
     std::lock_guard<std::mutex> lk(e->mu);
@@ -80,13 +80,15 @@ int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
                 const double a = -kTwoPi * (double)ex / (double)n_fft;
                 h1[(size_t)t * 16 + s] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
-        for (int m = 0; m < R3; ++m)
-            for (int s = 0; s < 16; ++s) {
-                const long ex = ((long)m * rev16h(s)) % T;
+        // tw2[q2][m] = scale * W_T^(m * q2): the R3 twiddles lane q2 applies to the
+        // inputs of its last-pass butterflies
+        for (int q2 = 0; q2 < 16; ++q2)
+            for (int m = 0; m < R3; ++m) {
+                const long ex = ((long)m * q2) % T;
                 const double a = -kTwoPi * (double)ex / (double)T;
                 const double c = std::cos(a), sn = std::sin(a);
-                h2u[(size_t)m * 16 + s] = make_float2((float)c, (float)sn);
-                h2s[(size_t)m * 16 + s] = make_float2((float)c * 0.0078125f, (float)sn * 0.0078125f);
+                h2u[(size_t)q2 * R3 + m] = make_float2((float)c, (float)sn);
+                h2s[(size_t)q2 * R3 + m] = make_float2((float)c * 0.0078125f, (float)sn * 0.0078125f);
             }
         HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
         HIP_TRY(hipMalloc(&tb.tw2_unit, h2u.size() * sizeof(float2)), -3);
@@ -135,9 +137,9 @@ bool desc_ok(const rtlws_spectra_desc* d)
 
 int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups)
 {
-    // 12 wavefronts per CU (3 per SIMD at <=168 VGPRs; LDS 12 x 8.5 KiB):
-    // 12, 6 or 3 workgroups per CU.  Persistent: each strides over the rows.
-    const int per_cu = 12 / (n_fft / 1024);
+    // 16 wavefronts per CU (4 per SIMD at <=128 VGPRs; LDS 16 x 8.5 KiB):
+    // 16, 8 or 4 workgroups per CU.  Persistent: each strides over the rows.
+    const int per_cu = 16 / (n_fft / 1024);
     long blocks = (long)e->cu_count * per_cu;
     if (blocks > ngroups) blocks = ngroups;
     return (int)(blocks < 1 ? 1 : blocks);

@@ -62,6 +62,36 @@ def synth_iq_torch(torch, nframes, samples_per_frame, seed, device):
     return out
 
 
+def init_distributed(torch, backend="nccl", device=None):
+    """One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE/
+    MASTER_*).  The data path never uses the group: it only carries the timing
+    barrier and the MAX-reduce of the elapsed time.  Returns (dist or None, world, rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        return None, 1, 0
+    import torch.distributed as dist
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
+    else:
+        dist.init_process_group(backend=backend)
+    return dist, world, rank
+
+
+def max_over_ranks(torch, dist, values, device=None):
+    """Element-wise MAX of a list of floats over all ranks (identity when dist is None)."""
+    if dist is None:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
+def whole_job_rate(world, steps, frames_per_step, elapsed_s):
+    """Every rank processes its own `frames_per_step` per step (weak scaling)."""
+    return world * steps * frames_per_step / elapsed_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,25 +100,23 @@ def main():
     ap.add_argument("--workload", default="batched_1024pt_64k_frames", choices=sorted(WORKLOADS))
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=0, help="override frames per step (experiments)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import rtlws
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL; timing barrier only
+    dist, world, rank = init_distributed(torch, "nccl", device)
 
     n_fft, k_avg, window, output, cic_r, frames = WORKLOADS[args.workload]
+    if args.frames > 0:
+        frames = args.frames - args.frames % k_avg
     spf = n_fft * max(cic_r, 1)
     eng = rtlws.Engine(local_rank)
     desc = rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
@@ -123,14 +151,11 @@ def main():
     elapsed = t1 - t0
     ev_ms = rtlws.hip_lib().rtlws_event_elapsed_ms(ev0, ev1)
 
-    if dist is not None:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(t[0]), float(t[1])
+    elapsed, ev_ms = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
 
     result = None
     if rank == 0:
-        value = world * args.steps * frames / elapsed
+        value = whole_job_rate(world, args.steps, frames, elapsed)
         bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r) * frames
         avg_launch_s = (ev_ms / 1e3) / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9

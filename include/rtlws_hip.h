@@ -108,6 +108,13 @@ typedef struct rtlws_spectra_desc {
 int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
                         long nframes, void* d_out, void* stream);
 
+/* The dB epilogue on its own (reference src/cbb_main.c:112,121-130) for sums
+ * that already live on the device: out[i] = clamp((int)(10*log10(|g*sums[i]/count|)),
+ * 0, 255), g = 10^(gain_db/10) with C integer division.  n values in, n bytes
+ * out; count must be > 0.  0 / -1 / -3. */
+int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int count, int gain_db,
+                            void* d_out_u8, void* stream);
+
 /* Which kernel a descriptor selects: 1 fused, 2 direct DFT, 0 unsupported. */
 int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* desc);
 

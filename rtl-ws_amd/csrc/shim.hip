@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -139,7 +140,11 @@ int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups)
 {
     // 16 wavefronts per CU (4 per SIMD at <=128 VGPRs; LDS 16 x 8.5 KiB):
     // 16, 8 or 4 workgroups per CU.  Persistent: each strides over the rows.
-    const int per_cu = 16 / (n_fft / 1024);
+    int per_cu = 16 / (n_fft / 1024);
+    if (const char* ov = getenv("RTLWS_BLOCKS_PER_CU")) {   // experiments only
+        const int v = atoi(ov);
+        if (v > 0) per_cu = v;
+    }
     long blocks = (long)e->cu_count * per_cu;
     if (blocks > ngroups) blocks = ngroups;
     return (int)(blocks < 1 ? 1 : blocks);
@@ -353,6 +358,25 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     }
     if (err != hipSuccess) {
         set_err("spectra kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int count, int gain_db,
+                            void* d_out, void* stream)
+{
+    g_err.clear();
+    if (!e || n < 0 || count <= 0 || (n > 0 && (!d_sums || !d_out))) {
+        g_err = "rtlws_payload_from_sums: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    const float lin = (float)(std::pow(10.0, (double)(gain_db / 10)) / (double)count);
+    hipError_t err = rtlws::launch_payload(d_sums, n, lin, reinterpret_cast<uint8_t*>(d_out),
+                                           pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("payload kernel launch", err);
         return -3;
     }
     return 0;

@@ -80,6 +80,25 @@ __global__ __launch_bounds__(256) void spectra_direct(const SpectraParams p)
 }
 
 
+// dB / truncate / clamp of reference src/cbb_main.c:125-128 as its own kernel.
+__global__ __launch_bounds__(256) void payload_kernel(const float* __restrict__ sums, int n,
+                                                      float lin_gain, uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float d = 10.0f * log10f(fabsf(sums[i] * lin_gain));
+        const unsigned m = (d >= 0.0f) ? (d <= 255.0f ? (unsigned)(int)d : 255u) : 0u;
+        out[i] = (uint8_t)m;
+    }
+}
+
+hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(payload_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_sums, n, lin_gain, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_spectra_direct(const SpectraParams& p, int in_kind, hipStream_t st)
 {
     const size_t lds_bytes = sizeof(float2) * (size_t)p.n_fft;

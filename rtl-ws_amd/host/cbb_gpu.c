@@ -1,0 +1,190 @@
+/* cbb_gpu.c -- cbb_main.h (drop-in boundary #2) over the HIP engine.
+ *
+ * Replaces reference src/cbb_main.c:1-153.  Per sensor buffer (worker thread):
+ * count samples, feed the decimator, and -- at most every 250 ms -- turn the
+ * first min(len/1024, 6) frames into ONE launch of the fused kernel (K =
+ * blocks, f32 power sums that stay on the device).  On the server thread,
+ * cbb_get_spectrum_payload runs the dB/clamp kernel on the published sums and
+ * brings back the 1024 bytes main.c sends to the browser.
+ *
+ * The sensor (rtl_sensor.h) and the signal source (signal_source.h) are NOT
+ * part of this file: they are the reference's own units, or the synthetic
+ * ones in synth_sensor.c / synth_signal_source.c.
+ */
+#include "cbb_main.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "host_ctx.h"
+#include "rtlws_hip.h"
+#include "signal_source.h"
+
+#define DEV_INDEX       0       /* reference src/cbb_main.c:15 */
+#define SPECTRUM_EST_MS 250     /* :16 */
+#define FFT_POINTS      1024    /* :17 */
+#define FFT_AVERAGE     6       /* :18 */
+
+static struct rtl_dev* g_dev = NULL;
+static struct rf_decimator* g_decim = NULL;
+static rtlws_engine* g_eng = NULL;
+
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;   /* device work + published state */
+static void* g_d_iq = NULL;             /* FFT_AVERAGE frames of cmplx_u8 */
+static float* g_d_work = NULL;          /* sums being produced            */
+static float* g_d_pub = NULL;           /* sums the server thread reads   */
+static void* g_d_payload = NULL;
+static cmplx_u8* g_h_iq = NULL;         /* pinned */
+static unsigned char* g_h_payload = NULL;
+static int g_pub_count = 0;             /* frames behind g_d_pub */
+static uint64_t g_last_est_ms = 0;
+static volatile int g_new_spectrum = 0;
+static uint64_t g_samples_seen = 0;
+
+static uint64_t now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);          /* as reference src/common.c:4-9 */
+    return (uint64_t)ts.tv_sec * 1000u + (uint64_t)ts.tv_nsec / 1000000u;
+}
+
+/* callback #1 (reference src/cbb_main.c:30-33): the reference prints a rate
+ * line every 60 s; the engine only keeps the count. */
+static void count_samples(const cmplx_u8* signal, int len)
+{
+    (void)signal;
+    g_samples_seen += (uint64_t)(len > 0 ? len : 0);
+}
+
+/* callback #2 (reference src/cbb_main.c:35-38) */
+static void decimate(const cmplx_u8* signal, int len)
+{
+    rf_decimator_decimate_cmplx_u8(g_decim, signal, len);
+}
+
+/* callback #3 (reference src/cbb_main.c:40-70) */
+static void estimate_spectrum(const cmplx_u8* signal, int len)
+{
+    int blocks = len / FFT_POINTS;
+    rtlws_spectra_desc d;
+
+    if (now_ms() < g_last_est_ms + SPECTRUM_EST_MS) return;      /* :46-47 */
+    blocks = blocks <= FFT_AVERAGE ? blocks : FFT_AVERAGE;        /* :49 */
+
+    pthread_mutex_lock(&g_mu);
+    if (blocks > 0) {
+        const size_t bytes = (size_t)blocks * FFT_POINTS * sizeof(cmplx_u8);
+        memset(&d, 0, sizeof d);
+        d.n_fft = FFT_POINTS;
+        d.k_avg = blocks;                       /* one output row = the whole average */
+        d.input = RTLWS_IN_CU8;
+        d.window = RTLWS_WIN_RECT;
+        d.output = RTLWS_OUT_POWER_SUM;
+        memcpy(g_h_iq, signal, bytes);
+        if (rtlws_copy_h2d(g_eng, g_d_iq, g_h_iq, bytes, NULL) ||
+            rtlws_spectra_batch(g_eng, &d, g_d_iq, blocks, g_d_work, NULL) ||
+            rtlws_stream_sync(g_eng, NULL)) {
+            fprintf(stderr, "rtlws: estimate_spectrum: device failure: %s\n", rtlws_last_error());
+            pthread_mutex_unlock(&g_mu);
+            return;                                               /* :54-58 */
+        }
+    }
+    g_last_est_ms = now_ms();                                     /* :61 */
+    g_new_spectrum = 1;                                           /* :62 */
+    {   /* publish: swap instead of the reference's 8 KiB memcpy (:64-69) */
+        float* t = g_d_pub;
+        g_d_pub = g_d_work;
+        g_d_work = t;
+        g_pub_count = blocks;
+    }
+    pthread_mutex_unlock(&g_mu);
+}
+
+void cbb_init(int decimated_bw_target_hz)
+{
+    rtl_init(&g_dev, DEV_INDEX);                                  /* :77 */
+
+    g_decim = rf_decimator_alloc();                               /* :79-80 */
+    rf_decimator_set_parameters(g_decim, rtl_sample_rate(g_dev),
+                                (int)(rtl_sample_rate(g_dev) / (uint32_t)decimated_bw_target_hz));
+
+    g_eng = rtlws_engine_create(rtlws_host_device());             /* replaces spectrum_alloc, :83 */
+    if (!g_eng) {
+        fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
+        abort();                                /* no CPU path to fall back to */
+    }
+    g_d_iq = rtlws_dev_alloc(g_eng, (size_t)FFT_AVERAGE * FFT_POINTS * sizeof(cmplx_u8));
+    g_d_work = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
+    g_d_pub = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
+    g_d_payload = rtlws_dev_alloc(g_eng, FFT_POINTS);
+    g_h_iq = (cmplx_u8*)rtlws_pinned_alloc((size_t)FFT_AVERAGE * FFT_POINTS * sizeof(cmplx_u8));
+    g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
+    if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_h_iq || !g_h_payload) {
+        fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
+        abort();
+    }
+    g_pub_count = 0;
+    g_last_est_ms = 0;
+    g_new_spectrum = 0;
+    g_samples_seen = 0;
+
+    signal_source_start(g_dev);                                   /* :85 */
+    signal_source_add_callback(count_samples);                    /* :86 */
+    signal_source_add_callback(decimate);                         /* :87 */
+    signal_source_add_callback(estimate_spectrum);                /* :88 */
+}
+
+struct rtl_dev* cbb_get_rtl_dev(void) { return g_dev; }          /* :91-94 */
+
+struct rf_decimator* cbb_rf_decimator(void) { return g_decim; }   /* :96-99 */
+
+int cbb_new_spectrum_available(void) { return g_new_spectrum; }   /* :101-104 */
+
+int cbb_get_spectrum_payload(char* buf, int buf_len, int spectrum_gain_db)
+{
+    int len = 0;
+    pthread_mutex_lock(&g_mu);
+    if (g_pub_count > 0) {                                        /* :121 */
+        if (rtlws_payload_from_sums(g_eng, g_d_pub, FFT_POINTS, g_pub_count, spectrum_gain_db,
+                                    g_d_payload, NULL) ||
+            rtlws_copy_d2h(g_eng, g_h_payload, g_d_payload, FFT_POINTS, NULL) ||
+            rtlws_stream_sync(g_eng, NULL)) {
+            fprintf(stderr, "rtlws: cbb_get_spectrum_payload: device failure: %s\n", rtlws_last_error());
+        } else {
+            len = buf_len < FFT_POINTS ? (buf_len > 0 ? buf_len : 0) : FFT_POINTS;
+            memcpy(buf, g_h_payload, (size_t)len);                /* :123-129 */
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+    g_new_spectrum = 0;                                           /* :132 */
+    return len;
+}
+
+void cbb_close(void)
+{
+    signal_source_remove_callbacks();                             /* :139 */
+    signal_source_stop();                                         /* :141 */
+    rf_decimator_free(g_decim);                                   /* :143 */
+    g_decim = NULL;
+    pthread_mutex_lock(&g_mu);
+    if (g_eng) {
+        rtlws_dev_free(g_eng, g_d_iq);
+        rtlws_dev_free(g_eng, g_d_work);
+        rtlws_dev_free(g_eng, g_d_pub);
+        rtlws_dev_free(g_eng, g_d_payload);
+        rtlws_pinned_free(g_h_iq);
+        rtlws_pinned_free(g_h_payload);
+        rtlws_engine_destroy(g_eng);                              /* replaces spectrum_free, :145 */
+        g_eng = NULL;
+    }
+    g_pub_count = 0;
+    pthread_mutex_unlock(&g_mu);
+    rtl_close(g_dev);                                             /* :149 */
+    g_dev = NULL;
+}
+
+/* test/diagnostic hook: complex samples the callbacks have seen so far */
+uint64_t rtlws_cbb_samples_seen(void) { return g_samples_seen; }

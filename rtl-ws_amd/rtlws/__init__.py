@@ -20,8 +20,11 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)                       # rtl-ws_amd/
 LIB_DIR = os.path.join(ROOT, "lib")
-HIP_LIB = os.path.join(LIB_DIR, "librtlws_hip.so")
+# RTLWS_HIP_LIB selects an experiment build (make variant ...); default: the product library
+HIP_LIB = os.environ.get("RTLWS_HIP_LIB") or os.path.join(LIB_DIR, "librtlws_hip.so")
 AMD_LIB = os.path.join(LIB_DIR, "librtlws_amd.so")
+CBB_LIB = os.path.join(LIB_DIR, "librtlws_cbb.so")       # include/cbb_main.h
+SYNTH_LIB = os.path.join(LIB_DIR, "librtlws_synth.so")   # synthetic rtl_sensor.h + signal_source.h
 
 IN_CU8, IN_CS32, IN_RF32 = 0, 1, 2
 WIN_RECT, WIN_HANN = 0, 1
@@ -59,7 +62,7 @@ HIP_SYMBOLS = [
     "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
     "rtlws_event_elapsed_ms", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
-    "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid",
+    "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
 ]
 AMD_SYMBOLS = [
     "spectrum_alloc", "spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32",
@@ -68,8 +71,16 @@ AMD_SYMBOLS = [
     "rf_decimator_remove_callbacks", "rf_decimator_free",
 ]
 
+CBB_SYMBOLS = ["cbb_init", "cbb_rf_decimator", "cbb_get_rtl_dev", "cbb_new_spectrum_available",
+               "cbb_get_spectrum_payload", "cbb_close"]
+SYNTH_SYMBOLS = ["rtl_init", "rtl_set_frequency", "rtl_set_sample_rate", "rtl_set_gain", "rtl_freq",
+                 "rtl_sample_rate", "rtl_gain", "rtl_read_async", "rtl_cancel", "rtl_close",
+                 "signal_source_start", "signal_source_add_callback",
+                 "signal_source_remove_callbacks", "signal_source_stop"]
+
 _hip = None
 _amd = None
+_cbb = None
 
 
 def _need(path):
@@ -110,6 +121,7 @@ def hip_lib():
         L.rtlws_spectra_kernel_kind.argtypes = [C.POINTER(SpectraDesc)]
         L.rtlws_cic_block_sums.argtypes = [vp, i, vp, l, vp, vp]
         L.rtlws_halfband.argtypes = [vp, vp, vp, l, vp]
+        L.rtlws_payload_from_sums.argtypes = [vp, vp, i, i, i, vp, vp]
         L.rtlws_spectra_grid.argtypes = [vp, C.POINTER(SpectraDesc), l, C.POINTER(i),
                                          C.POINTER(i), C.POINTER(i)]
         _hip = L
@@ -370,3 +382,35 @@ class RfDecimator:
             self.free()
         except Exception:
             pass
+
+
+# ---- boundary #2 (librtlws_cbb.so over the synthetic sensor) ------------------
+
+def cbb_lib():
+    """cbb_main.h entry points.  The sensor / signal-source symbols they need
+    come from librtlws_synth.so here (in rtl-ws they come from the server's own
+    rtl_sensor.c / signal_source.c)."""
+    global _cbb
+    if _cbb is None:
+        amd_lib()
+        _need(SYNTH_LIB)
+        _need(CBB_LIB)
+        C.CDLL(SYNTH_LIB, mode=C.RTLD_GLOBAL)
+        L = C.CDLL(CBB_LIB)
+        L.cbb_init.argtypes = [C.c_int]
+        L.cbb_init.restype = None
+        L.cbb_rf_decimator.restype = C.c_void_p
+        L.cbb_get_rtl_dev.restype = C.c_void_p
+        L.cbb_new_spectrum_available.restype = C.c_int
+        L.cbb_get_spectrum_payload.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cbb_get_spectrum_payload.restype = C.c_int
+        L.cbb_close.restype = None
+        L.rtlws_cbb_samples_seen.restype = C.c_uint64
+        _cbb = L
+    return _cbb
+
+
+def cbb_payload(gain_db, buf_len=8192):
+    buf = np.zeros(buf_len, dtype=np.uint8)
+    n = cbb_lib().cbb_get_spectrum_payload(_p(buf), buf_len, int(gain_db))
+    return buf[:n].copy()

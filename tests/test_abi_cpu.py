@@ -32,16 +32,26 @@ def test_every_declared_symbol_is_exported(built):
     for name in declared_hip:
         assert hasattr(hip, name), "librtlws_hip.so lacks " + name
     declared_amd = []
-    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "cbb_main.h"):
-        if os.path.exists(os.path.join(INCLUDE, h)):
-            fns = _declared_functions(h)
-            assert fns, h
-            declared_amd += fns
+    for h in ("spectrum.h", "resample.h", "rf_decimator.h"):
+        fns = _declared_functions(h)
+        assert fns, h
+        declared_amd += fns
     for name in declared_amd:
         assert hasattr(amd, name), "librtlws_amd.so lacks " + name
+    # boundary #2 and the synthetic seam live in their own libraries
+    synth = ctypes.CDLL(built.SYNTH_LIB, mode=ctypes.RTLD_GLOBAL)
+    cbb = ctypes.CDLL(built.CBB_LIB)
+    declared_cbb = _declared_functions("cbb_main.h")
+    declared_synth = _declared_functions("rtl_sensor.h") + _declared_functions("signal_source.h")
+    for name in declared_cbb:
+        assert hasattr(cbb, name), "librtlws_cbb.so lacks " + name
+    for name in declared_synth:
+        assert hasattr(synth, name), "librtlws_synth.so lacks " + name
     # the binding's own lists agree with the headers
     assert set(built.HIP_SYMBOLS) == set(declared_hip)
-    assert set(built.AMD_SYMBOLS) <= set(declared_amd)
+    assert set(built.AMD_SYMBOLS) == set(declared_amd)
+    assert set(built.CBB_SYMBOLS) == set(declared_cbb)
+    assert set(built.SYNTH_SYMBOLS) == set(declared_synth)
 
 
 def test_abi_struct_layouts(built):

@@ -1,0 +1,67 @@
+"""N > 1 plumbing of bench.py on CPU: two processes, gloo, 127.0.0.1.
+The data path has no collective (independent frames per GPU); what must be
+right is the rendezvous, the barrier-bracketed timing, the MAX over ranks and
+the whole-job rate.  The GPU step itself is replaced by a sleep here."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    import bench
+    dist, world, rank = bench.init_distributed(torch, backend="gloo")
+    assert world == 2 and dist is not None
+    steps, frames = 5, 1000
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    mine = elapsed
+    elapsed, other = bench.max_over_ranks(torch, dist, [elapsed, float(rank)])
+    if rank == 0:
+        print(json.dumps({"value": bench.whole_job_rate(world, steps, frames, elapsed),
+                          "elapsed": elapsed, "max_rank": other, "world": world}))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_two_rank_gloo_timing_and_aggregation(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["world"] == 2 and res["max_rank"] == 1.0
+    # both ranks are bracketed by barriers, so the job lasts as long as the slow rank
+    assert 0.19 < res["elapsed"] < 1.0
+    assert abs(res["value"] - 2 * 5 * 1000 / res["elapsed"]) < 1e-6
+
+
+def test_single_process_identity():
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    os.environ.pop("WORLD_SIZE", None)
+    dist, world, rank = bench.init_distributed(torch, backend="gloo")
+    assert dist is None and world == 1 and rank == 0
+    assert bench.max_over_ranks(torch, None, [1.5, 2.5]) == [1.5, 2.5]
+    assert bench.whole_job_rate(8, 10, 65536, 2.0) == 8 * 10 * 65536 / 2.0
+    assert bench.algorithmic_bytes_per_frame(1024, 1, 0) == 6144
+    assert bench.algorithmic_bytes_per_frame(4096, 8, 0) == 10240
+    assert bench.algorithmic_bytes_per_frame(2048, 1, 8) == 40960

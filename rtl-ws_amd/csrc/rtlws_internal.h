@@ -28,8 +28,21 @@ struct SpectraParams {
     float in_scale;        // direct kernel only (fused: folded into tw2)
 };
 
-// LDS the fused kernel needs, in float2 units: 16 padded rows + one spare slot.
-constexpr int fused_lds_f2(int n_fft) { return 16 * (n_fft / 16 + n_fft / 256) + 2; }
+// Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
+// second argument): N = 1024 fits 4 (121 VGPRs); the larger sizes carry R3 = 8
+// or 16 last-pass twiddles and a bigger last pass and spill at 128 VGPRs, so
+// they are built for 3 (<= 168 VGPRs).  RTLWS_WAVES_BIG overrides for experiments.
+#ifndef RTLWS_WAVES_BIG
+#define RTLWS_WAVES_BIG 3
+#endif
+constexpr int fused_waves_per_simd(int n_fft) { return n_fft == 1024 ? 4 : RTLWS_WAVES_BIG; }
+
+// LDS the fused kernel needs, in float2 units: 16 (padded) rows + one spare slot
+// (layouts: spectrum_fused.hip, "LDS layouts").
+constexpr int fused_lds_f2(int n_fft)
+{
+    return n_fft == 1024 ? 16 * 72 + 2 : 16 * (n_fft / 16 + n_fft / 256) + 2;
+}
 
 hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);
 hipError_t launch_spectra_fused_2048(const SpectraParams&, int in_kind, int blocks, hipStream_t);

@@ -138,9 +138,9 @@ bool desc_ok(const rtlws_spectra_desc* d)
 
 int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups)
 {
-    // 16 wavefronts per CU (4 per SIMD at <=128 VGPRs; LDS 16 x 8.5 KiB):
-    // 16, 8 or 4 workgroups per CU.  Persistent: each strides over the rows.
-    int per_cu = 16 / (n_fft / 1024);
+    // 4 x waves-per-SIMD wavefronts per CU, n_fft/1024 wavefronts per workgroup.
+    // Persistent: each workgroup strides over the output rows.
+    int per_cu = 4 * rtlws::fused_waves_per_simd(n_fft) / (n_fft / 1024);
     if (const char* ov = getenv("RTLWS_BLOCKS_PER_CU")) {   // experiments only
         const int v = atoi(ov);
         if (v > 0) per_cu = v;

@@ -195,3 +195,36 @@ def search_t1_general(N, max_f2):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "t1":
     search_t1_general(1024, 1300)
+
+
+def check_swizzled_1024():
+    """The XOR-swizzled transposition-1 layout and the padded transposition-2 layout used at N=1024."""
+    def h(q1):
+        return 8 * ((q1 >> 2) & 1) + (q1 & 1)
+
+    def lds1(q1, m1):
+        m2, r2 = m1 & 3, m1 >> 2
+        i, e = r2 >> 1, r2 & 1
+        g = 16 * (i >> 2) + 8 * ((i >> 1) & 1) + 2 * m2 + (i & 1)
+        return q1 * 64 + 2 * (g ^ h(q1)) + e
+
+    def lds2(q1, m2, q2):
+        return q2 * 72 + (q1 >> 2) * 18 + (q1 & 3) * 4 + m2
+
+    assert len({lds1(q, m) for q in range(16) for m in range(64)}) == 1024
+    assert len({lds2(q1, m2, q2) for q1 in range(16) for m2 in range(4) for q2 in range(16)}) == 1024
+    lanes = list(range(64))
+    w1 = sum(cycles([lds1(rev16(s), t) for t in lanes], W64, 2, 32) for s in range(16))
+    r1 = sum(cycles([lds1(t >> 2, 4 * (2 * i) + (t & 3)) for t in lanes], R128, 4, 64) for i in range(8))
+    for t in lanes:
+        for i in range(8):
+            assert lds1(t >> 2, 4 * (2 * i + 1) + (t & 3)) == lds1(t >> 2, 4 * (2 * i) + (t & 3)) + 1
+    w2 = sum(cycles([lds2(t >> 2, t & 3, rev16(s)) for t in lanes], W64, 2, 32) for s in range(16))
+    r2 = sum(cycles([lds2(4 * (t & 3) + (k >> 1), 2 * (k & 1), t >> 2) for t in lanes], R128, 4, 64) for k in range(8))
+    print("N=1024 swizzled: write1 %d (64) read1 %d (32) write2 %d (64) read2 %d (32); f2 used %d / %d"
+          % (w1, r1, w2, r2, 1 + max(lds1(q, m) for q in range(16) for m in range(64)),
+             1 + max(lds2(a, b, c) for a in range(16) for b in range(4) for c in range(16))))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "check":
+    check_swizzled_1024()

@@ -2,11 +2,11 @@
 # Effective shader clock under the fused kernel: GRBM_GUI_ACTIVE / 8 / duration on a
 # long dispatch (1 Mi frames ~ 1.3 ms), for the product build and the ablation builds.
 export TMPDIR=/tmp
-for lib in rtl-ws_amd/lib/librtlws_hip.so rtl-ws_amd/lib/variants/abl_nomem/librtlws_hip.so rtl-ws_amd/lib/variants/abl_nofft/librtlws_hip.so; do
+for lib in rtl-ws_amd/lib/librtlws_hip.so rtl-ws_amd/lib/variants/*/librtlws_hip.so; do
   tag=$(basename $(dirname $lib))
-  OUT=gpurun_out/clk_$tag
-  RTLWS_HIP_LIB=$PWD/$lib rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 30 --warmup 5 --sets 2 --frames 1048576 --no-cpu-baseline > /dev/null 2> $OUT.err
-  python3 - $OUT $tag <<'PY'
+  OUT=clk_$tag; mkdir -p /tmp/$OUT
+  RTLWS_HIP_LIB=$PWD/$lib rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/$OUT -- python3 bench.py --steps 30 --warmup 5 --sets 2 --frames 1048576 --no-cpu-baseline > /dev/null 2> /tmp/$OUT.err
+  python3 - /tmp/$OUT $tag <<'PY'
 import csv, glob, sys
 d, tag = sys.argv[1], sys.argv[2]
 f = glob.glob(d + '/*/*_counter_collection.csv')[0]

@@ -20,8 +20,10 @@
 struct dft_plan {
     int N;
     int pow2;
-    double* tw;     /* N/2 (pow2) or N twiddles exp(-2 pi i k / N), interleaved */
-    int* bitrev;    /* pow2 only */
+    double* tw;       /* non-pow2: N twiddles exp(-2 pi i k / N), interleaved */
+    double* st_re;    /* pow2: per-stage twiddles, stage with half-length h at offset h-1 */
+    double* st_im;
+    int* bitrev;      /* pow2 only */
 };
 
 #define MAX_PLANS 32
@@ -37,14 +39,18 @@ static struct dft_plan* plan_build(int N)
     p->N = N;
     p->pow2 = (N >= 2) && ((N & (N - 1)) == 0);
     if (p->pow2) {
-        int bits = 0, i;
+        int bits = 0, i, half;
         while ((1 << bits) < N) bits++;
-        p->tw = (double*)malloc(sizeof(double) * N);   /* N/2 complex */
-        for (k = 0; k < N / 2; k++) {
-            long double a = -two_pi * (long double)k / (long double)N;
-            p->tw[2 * k] = (double)cosl(a);
-            p->tw[2 * k + 1] = (double)sinl(a);
-        }
+        /* stage of butterfly span len = 2*half uses W_len^j, j < half; stored
+         * contiguously per stage so the inner loops are unit-stride */
+        p->st_re = (double*)malloc(sizeof(double) * N);
+        p->st_im = (double*)malloc(sizeof(double) * N);
+        for (half = 1; half < N; half <<= 1)
+            for (k = 0; k < half; k++) {
+                long double a = -two_pi * (long double)k / (long double)(2 * half);
+                p->st_re[half - 1 + k] = (double)cosl(a);
+                p->st_im[half - 1 + k] = (double)sinl(a);
+            }
         p->bitrev = (int*)malloc(sizeof(int) * N);
         for (i = 0; i < N; i++) {
             int r = 0, b;
@@ -78,34 +84,47 @@ static const struct dft_plan* plan_get(int N)
     return p;
 }
 
-static void dft_pow2(const struct dft_plan* p, const double* in, double* out)
+/* Radix-2 decimation-in-time on split re/im arrays that already hold the
+ * input in bit-reversed order; in place; f64 throughout. */
+static void dft_pow2_split(const struct dft_plan* p, double* restrict re, double* restrict im)
 {
     const int N = p->N;
-    int i, len;
-    for (i = 0; i < N; i++) {
-        int r = p->bitrev[i];
-        out[2 * r] = in[2 * i];
-        out[2 * r + 1] = in[2 * i + 1];
-    }
-    for (len = 2; len <= N; len <<= 1) {
-        const int half = len >> 1;
-        const int step = N / len;
-        int base, j;
+    int half, base, j;
+    for (half = 1; half < N; half <<= 1) {
+        const double* restrict wr = p->st_re + (half - 1);
+        const double* restrict wi = p->st_im + (half - 1);
+        const int len = 2 * half;
         for (base = 0; base < N; base += len) {
+            double* restrict ar = re + base;
+            double* restrict ai = im + base;
+            double* restrict br = re + base + half;
+            double* restrict bi = im + base + half;
             for (j = 0; j < half; j++) {
-                const double wr = p->tw[2 * (j * step)];
-                const double wi = p->tw[2 * (j * step) + 1];
-                double* a = out + 2 * (base + j);
-                double* b = out + 2 * (base + j + half);
-                const double tr = b[0] * wr - b[1] * wi;
-                const double ti = b[0] * wi + b[1] * wr;
-                b[0] = a[0] - tr;
-                b[1] = a[1] - ti;
-                a[0] += tr;
-                a[1] += ti;
+                const double tr = br[j] * wr[j] - bi[j] * wi[j];
+                const double ti = br[j] * wi[j] + bi[j] * wr[j];
+                br[j] = ar[j] - tr;
+                bi[j] = ai[j] - ti;
+                ar[j] += tr;
+                ai[j] += ti;
             }
         }
     }
+}
+
+static void dft_pow2(const struct dft_plan* p, const double* in, double* out)
+{
+    const int N = p->N;
+    double* re = (double*)malloc(sizeof(double) * 2 * N);
+    double* im = re + N;
+    int i;
+    for (i = 0; i < N; i++) {
+        const int r = p->bitrev[i];
+        re[r] = in[2 * i];
+        im[r] = in[2 * i + 1];
+    }
+    dft_pow2_split(p, re, im);
+    for (i = 0; i < N; i++) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; }
+    free(re);
 }
 
 void orc_dft_direct(int N, const double* in, double* out)
@@ -228,11 +247,49 @@ struct batch_job {
     double* out;
 };
 
+/* One power-of-two frame with thread-owned scratch: same arithmetic as
+ * orc_spectrum_add_cmplx_u8 / _s32 (conversion src/spectrum.c:54-58 / :72-76,
+ * window, forward DFT, src/spectrum.c:23-34), minus the per-call allocations. */
+static void fast_frame(const struct dft_plan* p, const uint8_t* u8, const int32_t* s32,
+                       const double* window, double* re, double* im, double* ps)
+{
+    const int N = p->N, offset = N / 2;
+    int i;
+    for (i = 0; i < N; i++) {
+        const int r = p->bitrev[i];
+        double a, b;
+        /* x / 128 written as x * 2^-7: the same f64 value, no divider */
+        if (u8) {
+            a = (((double)u8[2 * i]) - 128) * 0.0078125;
+            b = (((double)u8[2 * i + 1]) - 128) * 0.0078125;
+        } else {
+            a = ((double)s32[2 * i]) * 0.0078125;
+            b = ((double)s32[2 * i + 1]) * 0.0078125;
+        }
+        if (window) { a *= window[i]; b *= window[i]; }
+        re[r] = a;
+        im[r] = b;
+    }
+    dft_pow2_split(p, re, im);
+    /* slot i shows bin (offset + i) % N: first the upper half of the bins, then
+     * the slot of bin 0 (running left neighbour), then bins 1 .. offset-1 */
+    for (i = 0; i < N - offset; i++)
+        ps[i] += re[offset + i] * re[offset + i] + im[offset + i] * im[offset + i];
+    ps[N - offset] += ps[N - offset - 1];
+    for (i = N - offset + 1; i < N; i++) {
+        const int idx = i - (N - offset);
+        ps[i] += re[idx] * re[idx] + im[idx] * im[idx];
+    }
+}
+
 static void* batch_worker(void* arg)
 {
     struct batch_job* j = (struct batch_job*)arg;
     const int N = j->N, K = j->K, R = j->R;
+    const int pow2 = (N >= 2) && ((N & (N - 1)) == 0);
+    const struct dft_plan* plan = pow2 ? plan_get(N) : NULL;
     int32_t* dec = NULL;
+    double* scratch = pow2 ? (double*)malloc(sizeof(double) * 2 * N) : NULL;
     long row;
     if (R > 1) dec = (int32_t*)malloc(sizeof(int32_t) * 2 * N);
     for (row = j->row0; row < j->row1; row++) {
@@ -244,13 +301,17 @@ static void* batch_worker(void* arg)
             if (R > 1) {
                 int32_t st[4] = {0, 0, 0, 0};
                 orc_cic_decimate(R, j->src + frame * (size_t)N * R * 2, N * R, dec, N, st);
-                orc_spectrum_add_cmplx_s32(N, dec, j->window, ps, N);
+                if (pow2) fast_frame(plan, NULL, dec, j->window, scratch, scratch + N, ps);
+                else orc_spectrum_add_cmplx_s32(N, dec, j->window, ps, N);
             } else {
-                orc_spectrum_add_cmplx_u8(N, j->src + frame * (size_t)N * 2, j->window, ps, N);
+                const uint8_t* src = j->src + frame * (size_t)N * 2;
+                if (pow2) fast_frame(plan, src, NULL, j->window, scratch, scratch + N, ps);
+                else orc_spectrum_add_cmplx_u8(N, src, j->window, ps, N);
             }
         }
     }
     free(dec);
+    free(scratch);
     return NULL;
 }
 

@@ -41,7 +41,7 @@ constexpr int fused_waves_per_simd(int n_fft) { return n_fft == 1024 ? 4 : RTLWS
 // (layouts: spectrum_fused.hip, "LDS layouts").
 constexpr int fused_lds_f2(int n_fft)
 {
-    return n_fft == 1024 ? 16 * 72 + 2 : 16 * (n_fft / 16 + n_fft / 256) + 2;
+    return 16 * 18 * (n_fft / 256) + 2;     // transposition 2 is the larger of the two
 }
 
 hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);

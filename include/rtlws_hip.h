@@ -63,6 +63,8 @@ int rtlws_stream_sync(rtlws_engine* e, void* stream);
 void* rtlws_event_create(void);
 void rtlws_event_destroy(void* ev);
 int rtlws_event_record(void* ev, rtlws_engine* e, void* stream);
+/* Block the calling thread until the event has completed. 0 / -3. */
+int rtlws_event_sync(void* ev);
 /* Synchronises on `stop`; returns milliseconds, or a negative value. */
 float rtlws_event_elapsed_ms(void* start, void* stop);
 

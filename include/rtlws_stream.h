@@ -1,0 +1,65 @@
+/*
+ * rtlws_stream.h -- host-fed streaming front end of the spectrum engine.
+ *
+ * What the live server needs once it stops throwing away 122 of every 128
+ * frames (reference src/cbb_main.c:46-49 transforms at most 6 frames per
+ * 250 ms): sensor buffers arrive on the host (reference
+ * src/signal_source.c:29-35: 131 072 samples per callback with librtlsdr's
+ * defaults), are staged in a pinned ring, copied to the device
+ * asynchronously, transformed by the fused kernel and the results copied
+ * back -- each chunk on the stream's own HIP stream, several chunks in
+ * flight, completion reported in order on a worker thread.
+ *
+ * One stream per sensor; streams on different devices (or on the same one) are
+ * independent: BASELINE.json configs[4] is eight of these, one per GPU, no
+ * collective.  The throughput of this path is PCIe-bound (2 bytes in and
+ * 4/K bytes out per sample); it is never what bench.py reports as `value`.
+ */
+#ifndef RTLWS_STREAM_H
+#define RTLWS_STREAM_H
+
+#include "rtlws_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtlws_stream rtlws_stream;
+
+/* Called on the stream's worker thread, in push order, once a chunk's results
+ * are in host memory.  `rows` points at rows_in_chunk * n_fft outputs (f32, or
+ * bytes for RTLWS_OUT_PAYLOAD_U8) valid only during the call. */
+typedef void (*rtlws_stream_callback)(const void* rows, long nrows, long first_frame,
+                                      double latency_ms, void* user);
+
+typedef struct rtlws_stream_stats {
+    long chunks_pushed;
+    long chunks_done;
+    long chunks_dropped;       /* rtlws_stream_push(..., block = 0) found the ring full */
+    long frames_done;
+    double latency_ms_avg;     /* push -> results on the host */
+    double latency_ms_max;
+} rtlws_stream_stats;
+
+/* frames_per_chunk must be a multiple of desc->k_avg; ring_slots >= 2 chunks may
+ * be in flight.  NULL on failure (rtlws_last_error). */
+rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                int ring_slots, rtlws_stream_callback cb, void* user);
+
+/* Hand over one chunk of frames_per_chunk frames of host IQ (copied before the
+ * call returns).  block != 0: wait for a free ring slot; block == 0: count a
+ * drop and return 1 when the ring is full.  0 on success, -1 bad argument,
+ * -3 device failure. */
+int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block);
+
+/* Wait until every pushed chunk has been delivered. */
+int rtlws_stream_flush(rtlws_stream* s);
+
+void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out);
+
+void rtlws_stream_close(rtlws_stream* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTLWS_STREAM_H */

@@ -276,6 +276,12 @@ int rtlws_event_record(void* ev, rtlws_engine* e, void* stream)
     return 0;
 }
 
+int rtlws_event_sync(void* ev)
+{
+    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)), -3);
+    return 0;
+}
+
 float rtlws_event_elapsed_ms(void* start, void* stop)
 {
     float ms = -1.0f;

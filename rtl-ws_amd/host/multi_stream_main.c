@@ -1,0 +1,140 @@
+/* multi_stream_main.c -- BASELINE.json configs[4] driver: S independent IQ
+ * streams, stream i on device (i % ndev), one producer thread each, no
+ * collective.  Paced mode feeds every stream 131 072-sample buffers at a given
+ * sample rate (2.4 MS/s -> 2343.75 spectra/s/stream) and reports drops and
+ * latency; unpaced mode pushes as fast as the host link allows.
+ *
+ *   rtlws_multi_stream [--streams S] [--seconds T] [--rate HZ | --unpaced]
+ *                      [--nfft N] [--k K]
+ * Prints one JSON line.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "rtlws_stream.h"
+
+#define BUF_SAMPLES 131072
+
+struct producer {
+    int id, device;
+    double rate_hz, seconds;
+    int unpaced;
+    rtlws_spectra_desc desc;
+    rtlws_stream* st;
+    rtlws_stream_stats stats;
+    double elapsed_s;
+    volatile double checksum;
+    long rows_seen;
+};
+
+static void on_rows(const void* rows, long nrows, long first_frame, double latency_ms, void* user)
+{
+    struct producer* p = (struct producer*)user;
+    (void)first_frame; (void)latency_ms;
+    p->checksum += ((const float*)rows)[0];      /* touch the data like a consumer would */
+    p->rows_seen += nrows;
+}
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* producer_main(void* arg)
+{
+    struct producer* p = (struct producer*)arg;
+    const long frames = BUF_SAMPLES / p->desc.n_fft;
+    unsigned char* buf = (unsigned char*)malloc(2 * BUF_SAMPLES);
+    unsigned x = 2463534242u + 977u * (unsigned)p->id;
+    double t0, next;
+    long i;
+    for (i = 0; i < BUF_SAMPLES; i++) {      /* tone + noise, different per stream */
+        double ph = 2.0 * 3.14159265358979 * (0.05 + 0.1 * p->id) * (double)i;
+        double re, im;
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        re = 0.6 * cos(ph) + ((double)(x & 0xffff) / 65536.0 - 0.5) * 0.2;
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        im = 0.6 * sin(ph) + ((double)(x & 0xffff) / 65536.0 - 0.5) * 0.2;
+        buf[2 * i] = (unsigned char)fmin(255.0, fmax(0.0, floor(re * 128.0 + 128.5)));
+        buf[2 * i + 1] = (unsigned char)fmin(255.0, fmax(0.0, floor(im * 128.0 + 128.5)));
+    }
+    p->st = rtlws_stream_open(p->device, &p->desc, frames, 4, on_rows, p);
+    if (!p->st) { fprintf(stderr, "stream %d: open failed: %s\n", p->id, rtlws_last_error()); free(buf); return NULL; }
+    t0 = now_s();
+    next = t0;
+    while (now_s() - t0 < p->seconds) {
+        if (!p->unpaced) {
+            struct timespec ts;
+            next += (double)BUF_SAMPLES / p->rate_hz;
+            ts.tv_sec = (time_t)next;
+            ts.tv_nsec = (long)((next - floor(next)) * 1e9);
+            clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, NULL);
+            rtlws_stream_push(p->st, buf, 0);     /* a real sensor cannot wait: full ring = drop */
+        } else {
+            rtlws_stream_push(p->st, buf, 1);
+        }
+    }
+    rtlws_stream_flush(p->st);
+    p->elapsed_s = now_s() - t0;
+    rtlws_stream_get_stats(p->st, &p->stats);
+    rtlws_stream_close(p->st);
+    free(buf);
+    return NULL;
+}
+
+int main(int argc, char** argv)
+{
+    int streams = 8, nfft = 1024, k = 1, unpaced = 0, i, ndev;
+    double seconds = 3.0, rate = 2400000.0;
+    struct producer* ps;
+    pthread_t* th;
+    double total_rate = 0.0, lat_max = 0.0, lat_avg = 0.0;
+    long drops = 0, frames = 0;
+    for (i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--seconds") && i + 1 < argc) seconds = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--rate") && i + 1 < argc) rate = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--nfft") && i + 1 < argc) nfft = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--k") && i + 1 < argc) k = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--unpaced")) unpaced = 1;
+    }
+    ndev = rtlws_device_count();
+    if (ndev < 1) { fprintf(stderr, "no HIP device (there is no CPU path)\n"); return 2; }
+    ps = (struct producer*)calloc((size_t)streams, sizeof(*ps));
+    th = (pthread_t*)calloc((size_t)streams, sizeof(*th));
+    for (i = 0; i < streams; i++) {
+        ps[i].id = i;
+        ps[i].device = i % ndev;
+        ps[i].rate_hz = rate;
+        ps[i].seconds = seconds;
+        ps[i].unpaced = unpaced;
+        ps[i].desc.n_fft = nfft;
+        ps[i].desc.k_avg = k;
+        ps[i].desc.input = RTLWS_IN_CU8;
+        ps[i].desc.window = RTLWS_WIN_RECT;
+        ps[i].desc.output = RTLWS_OUT_POWER_SUM;
+        pthread_create(&th[i], NULL, producer_main, &ps[i]);
+    }
+    for (i = 0; i < streams; i++) pthread_join(th[i], NULL);
+    for (i = 0; i < streams; i++) {
+        if (ps[i].elapsed_s > 0) total_rate += (double)ps[i].stats.frames_done / ps[i].elapsed_s;
+        drops += ps[i].stats.chunks_dropped;
+        frames += ps[i].stats.frames_done;
+        lat_avg += ps[i].stats.latency_ms_avg / streams;
+        if (ps[i].stats.latency_ms_max > lat_max) lat_max = ps[i].stats.latency_ms_max;
+    }
+    printf("{\"streams\": %d, \"devices\": %d, \"paced\": %s, \"rate_hz\": %.0f, \"n_fft\": %d, \"k_avg\": %d, "
+           "\"seconds\": %.2f, \"spectra_per_s_total\": %.1f, \"spectra_per_s_per_stream\": %.1f, "
+           "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}\n",
+           streams, ndev, unpaced ? "false" : "true", rate, nfft, k, seconds, total_rate,
+           total_rate / streams, frames, drops, lat_avg, lat_max);
+    free(ps);
+    free(th);
+    return 0;
+}

@@ -1,0 +1,219 @@
+/* stream_gpu.c -- rtlws_stream.h: pinned ring -> async H2D -> fused kernel ->
+ * async D2H, several chunks in flight, in-order completion on a worker thread.
+ * Plain C over include/rtlws_hip.h. */
+#include "rtlws_stream.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+enum { SLOT_FREE = 0, SLOT_IN_FLIGHT = 1 };
+
+struct slot {
+    void* h_in;      /* pinned */
+    void* h_out;     /* pinned */
+    void* d_in;
+    void* d_out;
+    void* done;      /* event recorded after the D2H copy */
+    int state;
+    long first_frame;
+    double t_push_ms;
+};
+
+struct rtlws_stream {
+    rtlws_engine* eng;
+    rtlws_spectra_desc desc;
+    long frames_per_chunk, rows_per_chunk;
+    size_t in_bytes, out_bytes;
+    int nslots;
+    struct slot* slots;
+    int head, tail;                  /* next slot to fill / next to complete */
+    long next_frame;
+    rtlws_stream_callback cb;
+    void* user;
+    pthread_t worker;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_free;
+    int closing;
+    rtlws_stream_stats st;
+    double lat_sum;
+};
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+static size_t sample_bytes(const rtlws_spectra_desc* d)
+{
+    const size_t r = d->cic_r > 1 ? (size_t)d->cic_r : 1u;
+    switch (d->input) {
+    case RTLWS_IN_CS32: return 8;
+    case RTLWS_IN_RF32: return 4;
+    default: return 2 * r;
+    }
+}
+
+static void* worker_main(void* arg)
+{
+    rtlws_stream* s = (rtlws_stream*)arg;
+    for (;;) {
+        struct slot* sl;
+        double lat;
+        pthread_mutex_lock(&s->mu);
+        while (!s->closing && s->slots[s->tail].state != SLOT_IN_FLIGHT)
+            pthread_cond_wait(&s->cv_work, &s->mu);
+        if (s->slots[s->tail].state != SLOT_IN_FLIGHT) {      /* closing and drained */
+            pthread_mutex_unlock(&s->mu);
+            return NULL;
+        }
+        sl = &s->slots[s->tail];
+        pthread_mutex_unlock(&s->mu);
+
+        if (rtlws_event_sync(sl->done) != 0)
+            fprintf(stderr, "rtlws_stream: device failure: %s\n", rtlws_last_error());
+        lat = now_ms() - sl->t_push_ms;
+        if (s->cb) s->cb(sl->h_out, s->rows_per_chunk, sl->first_frame, lat, s->user);
+
+        pthread_mutex_lock(&s->mu);
+        sl->state = SLOT_FREE;
+        s->tail = (s->tail + 1) % s->nslots;
+        s->st.chunks_done++;
+        s->st.frames_done += s->frames_per_chunk;
+        s->lat_sum += lat;
+        if (lat > s->st.latency_ms_max) s->st.latency_ms_max = lat;
+        pthread_cond_broadcast(&s->cv_free);
+        pthread_mutex_unlock(&s->mu);
+    }
+}
+
+rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                int ring_slots, rtlws_stream_callback cb, void* user)
+{
+    rtlws_stream* s;
+    int i;
+    if (!desc || rtlws_spectra_kernel_kind(desc) == 0 || frames_per_chunk <= 0 ||
+        frames_per_chunk % desc->k_avg || ring_slots < 2)
+        return NULL;
+    s = (rtlws_stream*)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->eng = rtlws_engine_create(device);
+    if (!s->eng) { free(s); return NULL; }
+    s->desc = *desc;
+    s->frames_per_chunk = frames_per_chunk;
+    s->rows_per_chunk = frames_per_chunk / desc->k_avg;
+    s->in_bytes = (size_t)frames_per_chunk * (size_t)desc->n_fft * sample_bytes(desc);
+    s->out_bytes = (size_t)s->rows_per_chunk * (size_t)desc->n_fft *
+                   (desc->output == RTLWS_OUT_PAYLOAD_U8 ? 1u : 4u);
+    s->nslots = ring_slots;
+    s->cb = cb;
+    s->user = user;
+    s->slots = (struct slot*)calloc((size_t)ring_slots, sizeof(struct slot));
+    pthread_mutex_init(&s->mu, NULL);
+    pthread_cond_init(&s->cv_work, NULL);
+    pthread_cond_init(&s->cv_free, NULL);
+    for (i = 0; i < ring_slots; i++) {
+        struct slot* sl = &s->slots[i];
+        sl->h_in = rtlws_pinned_alloc(s->in_bytes);
+        sl->h_out = rtlws_pinned_alloc(s->out_bytes);
+        sl->d_in = rtlws_dev_alloc(s->eng, s->in_bytes);
+        sl->d_out = rtlws_dev_alloc(s->eng, s->out_bytes);
+        sl->done = rtlws_event_create();
+        if (!sl->h_in || !sl->h_out || !sl->d_in || !sl->d_out || !sl->done) {
+            rtlws_stream_close(s);
+            return NULL;
+        }
+    }
+    if (pthread_create(&s->worker, NULL, worker_main, s) != 0) {
+        rtlws_stream_close(s);
+        return NULL;
+    }
+    return s;
+}
+
+int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block)
+{
+    struct slot* sl;
+    int rc = 0;
+    if (!s || !iq_host) return -1;
+    pthread_mutex_lock(&s->mu);
+    while (s->slots[s->head].state != SLOT_FREE) {
+        if (!block) {
+            s->st.chunks_dropped++;
+            s->next_frame += s->frames_per_chunk;      /* the dropped frames keep their numbers */
+            pthread_mutex_unlock(&s->mu);
+            return 1;
+        }
+        pthread_cond_wait(&s->cv_free, &s->mu);
+    }
+    sl = &s->slots[s->head];
+    sl->first_frame = s->next_frame;
+    sl->t_push_ms = now_ms();
+    memcpy(sl->h_in, iq_host, s->in_bytes);
+    /* one in-order queue per sensor: copy in, transform, copy out, mark */
+    if (rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, NULL) ||
+        rtlws_spectra_batch(s->eng, &s->desc, sl->d_in, s->frames_per_chunk, sl->d_out, NULL) ||
+        rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, NULL) ||
+        rtlws_event_record(sl->done, s->eng, NULL)) {
+        rc = -3;
+    } else {
+        sl->state = SLOT_IN_FLIGHT;
+        s->head = (s->head + 1) % s->nslots;
+        s->next_frame += s->frames_per_chunk;
+        s->st.chunks_pushed++;
+        pthread_cond_signal(&s->cv_work);
+    }
+    pthread_mutex_unlock(&s->mu);
+    return rc;
+}
+
+int rtlws_stream_flush(rtlws_stream* s)
+{
+    if (!s) return -1;
+    pthread_mutex_lock(&s->mu);
+    while (s->st.chunks_done < s->st.chunks_pushed) pthread_cond_wait(&s->cv_free, &s->mu);
+    pthread_mutex_unlock(&s->mu);
+    return 0;
+}
+
+void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out)
+{
+    pthread_mutex_lock(&s->mu);
+    *out = s->st;
+    out->latency_ms_avg = s->st.chunks_done ? s->lat_sum / (double)s->st.chunks_done : 0.0;
+    pthread_mutex_unlock(&s->mu);
+}
+
+void rtlws_stream_close(rtlws_stream* s)
+{
+    int i;
+    if (!s) return;
+    if (s->worker) {
+        rtlws_stream_flush(s);
+        pthread_mutex_lock(&s->mu);
+        s->closing = 1;
+        pthread_cond_broadcast(&s->cv_work);
+        pthread_mutex_unlock(&s->mu);
+        pthread_join(s->worker, NULL);
+    }
+    for (i = 0; i < s->nslots; i++) {
+        struct slot* sl = &s->slots[i];
+        rtlws_pinned_free(sl->h_in);
+        rtlws_pinned_free(sl->h_out);
+        if (s->eng) {
+            rtlws_dev_free(s->eng, sl->d_in);
+            rtlws_dev_free(s->eng, sl->d_out);
+        }
+        rtlws_event_destroy(sl->done);
+    }
+    free(s->slots);
+    rtlws_engine_destroy(s->eng);
+    pthread_mutex_destroy(&s->mu);
+    pthread_cond_destroy(&s->cv_work);
+    pthread_cond_destroy(&s->cv_free);
+    free(s);
+}

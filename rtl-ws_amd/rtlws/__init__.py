@@ -61,9 +61,11 @@ HIP_SYMBOLS = [
     "rtlws_last_error", "rtlws_dev_alloc", "rtlws_dev_free", "rtlws_pinned_alloc",
     "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
-    "rtlws_event_elapsed_ms", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
+    "rtlws_event_elapsed_ms", "rtlws_event_sync", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
     "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
 ]
+STREAM_SYMBOLS = ["rtlws_stream_open", "rtlws_stream_push", "rtlws_stream_flush",
+                  "rtlws_stream_get_stats", "rtlws_stream_close"]
 AMD_SYMBOLS = [
     "spectrum_alloc", "spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32",
     "spectrum_free", "cic_decimate", "halfband_decimate", "rf_decimator_alloc",
@@ -116,6 +118,7 @@ def hip_lib():
         L.rtlws_event_destroy.argtypes = [vp]
         L.rtlws_event_record.argtypes = [vp, vp, vp]
         L.rtlws_event_elapsed_ms.argtypes = [vp, vp]
+        L.rtlws_event_sync.argtypes = [vp]
         L.rtlws_event_elapsed_ms.restype = C.c_float
         L.rtlws_spectra_batch.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
         L.rtlws_spectra_kernel_kind.argtypes = [C.POINTER(SpectraDesc)]

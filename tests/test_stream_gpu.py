@@ -1,0 +1,107 @@
+"""Host-fed streaming path (include/rtlws_stream.h): pinned ring, async copies,
+in-order completion -- and the configs[4] driver built on it."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import rel_err, EPS_K1, EPS_STRICT, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+class Stats(C.Structure):
+    _fields_ = [("chunks_pushed", C.c_long), ("chunks_done", C.c_long), ("chunks_dropped", C.c_long),
+                ("frames_done", C.c_long), ("latency_ms_avg", C.c_double), ("latency_ms_max", C.c_double)]
+
+
+CB = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long, C.c_double, C.c_void_p)
+
+
+def _lib(built):
+    L = built.amd_lib()
+    L.rtlws_stream_open.argtypes = [C.c_int, C.POINTER(built.SpectraDesc), C.c_long, C.c_int, CB, C.c_void_p]
+    L.rtlws_stream_open.restype = C.c_void_p
+    L.rtlws_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.rtlws_stream_flush.argtypes = [C.c_void_p]
+    L.rtlws_stream_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.rtlws_stream_close.argtypes = [C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("K", [1, 8])
+def test_stream_results_in_order_and_equal_to_oracle(built, oracle, K):
+    from rtlws import synth
+    L = _lib(built)
+    N, frames_per_chunk, nchunks = 1024, 128, 12
+    iq = synth.tone_noise_iq(frames_per_chunk * nchunks, N, seed=K)
+    got, firsts = [], []
+
+    @CB
+    def cb(rows, nrows, first_frame, lat, user):
+        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_float)), shape=(nrows, N))
+        got.append(a.copy())
+        firsts.append(first_frame)
+
+    desc = built.make_desc(N, k_avg=K)
+    s = L.rtlws_stream_open(0, C.byref(desc), frames_per_chunk, 3, cb, None)
+    assert s
+    for c in range(nchunks):
+        chunk = np.ascontiguousarray(iq[c * frames_per_chunk:(c + 1) * frames_per_chunk])
+        assert L.rtlws_stream_push(s, chunk.ctypes.data_as(C.c_void_p), 1) == 0
+    assert L.rtlws_stream_flush(s) == 0
+    st = Stats()
+    L.rtlws_stream_get_stats(s, C.byref(st))
+    L.rtlws_stream_close(s)
+    assert (st.chunks_pushed, st.chunks_done, st.chunks_dropped) == (nchunks, nchunks, 0)
+    assert st.frames_done == frames_per_chunk * nchunks and st.latency_ms_max > 0
+    assert firsts == [c * frames_per_chunk for c in range(nchunks)]
+    ref = oracle.batch_spectra_u8(iq, N, K=K, nthreads=8)
+    assert rel_err(np.concatenate(got), ref, EPS_K1 if K == 1 else EPS_STRICT).max() <= TOL
+
+
+def test_stream_drops_when_ring_is_full_and_not_blocking(built):
+    L = _lib(built)
+    N, frames_per_chunk = 4096, 512            # 4 MiB chunks: slow enough to fill a 2-slot ring
+    import time
+
+    @CB
+    def cb(rows, nrows, first_frame, lat, user):
+        time.sleep(0.02)                        # a slow consumer
+
+    desc = built.make_desc(N)
+    s = L.rtlws_stream_open(0, C.byref(desc), frames_per_chunk, 2, cb, None)
+    chunk = np.zeros((frames_per_chunk, N, 2), dtype=np.uint8)
+    rcs = [L.rtlws_stream_push(s, chunk.ctypes.data_as(C.c_void_p), 0) for _ in range(12)]
+    L.rtlws_stream_flush(s)
+    st = Stats()
+    L.rtlws_stream_get_stats(s, C.byref(st))
+    L.rtlws_stream_close(s)
+    assert set(rcs) <= {0, 1} and rcs.count(1) == st.chunks_dropped > 0
+    assert st.chunks_done == st.chunks_pushed == rcs.count(0)
+
+
+def test_bad_open_arguments(built):
+    L = _lib(built)
+    cb = CB(lambda *a: None)
+    d = built.make_desc(1024, k_avg=3)
+    assert not L.rtlws_stream_open(0, C.byref(d), 128, 3, cb, None)       # 128 % 3 != 0
+    d = built.make_desc(1024)
+    assert not L.rtlws_stream_open(0, C.byref(d), 128, 1, cb, None)       # needs >= 2 slots
+    assert not L.rtlws_stream_open(0, C.byref(d), 0, 3, cb, None)
+
+
+def test_multi_stream_driver_realtime_no_drops(built):
+    """configs[4] on the one GPU this box has: 4 paced 2.4 MS/s streams share device 0."""
+    exe = os.path.join(built.LIB_DIR, "rtlws_multi_stream")
+    out = subprocess.run([exe, "--streams", "4", "--seconds", "1.5", "--rate", "2400000"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["chunks_dropped"] == 0
+    # 2.4 MS/s / 1024 = 2343.75 spectra/s per stream
+    assert 0.9 * 2343.75 < r["spectra_per_s_per_stream"] < 1.1 * 2343.75
+    assert r["latency_ms_max"] < 50

@@ -35,10 +35,15 @@ WORKLOADS = {
     "batched_1024pt_64k_frames": (1024, 1, "rect", "power_sum", 0, 65536),
     "hann_4096pt_k8_db": (4096, 8, "hann", "mean_db", 0, 16384),
     "cic8_2048pt": (2048, 1, "rect", "power_sum", 8, 8192),
+    # stand-alone CIC (reference src/resample.c:6-45): "frame" = 2048 decimated outputs,
+    # 2*8*2048 bytes in, 8*2048 bytes out; unit reported: decimated samples/s
+    "cic8_block_sums": (2048, 1, "rect", "cs32", 8, 8192),
 }
 
 
-def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r):
+def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum"):
+    if output == "cs32":                       # stand-alone CIC: cmplx_s32 out
+        return 2 * n_fft * cic_r + 8 * n_fft
     return 2 * n_fft * max(cic_r, 1) + 4 * n_fft // k_avg
 
 
@@ -119,17 +124,26 @@ def main():
         frames = args.frames - args.frames % k_avg
     spf = n_fft * max(cic_r, 1)
     eng = rtlws.Engine(local_rank)
-    desc = rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
+    cic_only = (output == "cs32")
+    desc = None if cic_only else rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
     rows = frames // k_avg
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run); "
+              "reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
 
     # device-resident inputs / outputs, allocated by torch (plumbing only)
     ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(args.sets)]
-    outs = [torch.empty((rows, n_fft), dtype=torch.float32, device=device) for _ in range(args.sets)]
+    out_dtype = torch.int32 if cic_only else torch.float32
+    out_cols = 2 * n_fft if cic_only else n_fft
+    outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(args.sets)]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
         s = i % args.sets
-        eng.spectra_batch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
+        if cic_only:
+            eng.cic_block_sums(cic_r, ins[s].data_ptr(), frames * n_fft, outs[s].data_ptr(), stream=stream)
+        else:
+            eng.spectra_batch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
 
     for i in range(args.warmup):
         step(i)
@@ -156,7 +170,7 @@ def main():
     result = None
     if rank == 0:
         value = whole_job_rate(world, args.steps, frames, elapsed)
-        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r) * frames
+        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output) * frames
         avg_launch_s = (ev_ms / 1e3) / args.steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic = None
@@ -166,10 +180,13 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        if cic_only:
+            value *= n_fft                      # decimated samples per second
         result = {
-            "metric": "spectra/s (1024-pt IQ frames)" if n_fft == 1024 else "spectra/s (%d-pt IQ frames)" % n_fft,
+            "metric": ("decimated samples/s (CIC R=%d)" % cic_r) if cic_only else
+                      ("spectra/s (1024-pt IQ frames)" if n_fft == 1024 else "spectra/s (%d-pt IQ frames)" % n_fft),
             "value": value,
-            "unit": "spectra/s",
+            "unit": "samples/s" if cic_only else "spectra/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -177,7 +194,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "int32" if cic_only else "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "n_fft": n_fft, "frames_per_step": frames,
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
@@ -194,13 +211,19 @@ def main():
         nchk = 256 * k_avg
         host_in = ins[0][:nchk].cpu().numpy()
         got = outs[0][:256].cpu().numpy().astype(np.float64)
-        if cic_r > 1:
+        if cic_only:
+            want = (host_in.astype(np.int32) - 128).reshape(-1, cic_r, 2).sum(axis=1).reshape(nchk, -1)
+            result["parity"] = {"frames": nchk, "bit_exact": bool(np.array_equal(outs[0][:nchk].cpu().numpy(), want))}
+            ref = None
+        elif cic_r > 1:
             ref = po.batch_spectra_cic_u8(host_in, n_fft, cic_r, K=k_avg, nthreads=8)
         else:
             ref = po.batch_spectra_u8(host_in, n_fft, K=k_avg, nthreads=8,
                                       window=None if window == "rect" else
                                       (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)))
-        if output == "mean_db":
+        if ref is None:
+            pass
+        elif output == "mean_db":
             ref = 10 * np.log10(ref / k_avg)
             result["parity"] = {"max_abs_db_err": float(np.abs(got - ref).max()), "frames": nchk}
         else:
@@ -220,16 +243,29 @@ def main():
             reps, t_cpu = 0, 0.0
             while t_cpu < 3.0 and reps < 20:       # bounded: a few seconds of CPU work
                 c0 = time.perf_counter()
-                if cic_r > 1:
+                if cic_only:                   # one thread: the loop carries a dependency
+                    if po.ref_available():     # the reference's own object code (oracle/_ref)
+                        po.ref_cic_decimate(cic_r, host.reshape(-1, 2))
+                    else:
+                        po.cic_decimate(cic_r, host.reshape(-1, 2))
+                elif cic_r > 1:
                     po.batch_spectra_cic_u8(host, n_fft, cic_r, K=k_avg, nthreads=cores)
                 else:
                     po.batch_spectra_u8(host, n_fft, K=k_avg, nthreads=cores)
                 t_cpu += time.perf_counter() - c0
                 reps += 1
-            result["cpu_baseline"] = {
-                "value": reps * sample / t_cpu, "unit": "spectra/s", "cores": cores, "kind": "port",
-                "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
-                          "(oracle/rtlws_oracle.c) on %d pthreads" % (sample, frames, reps, cores)}
+            if cic_only:
+                result["cpu_baseline"] = {
+                    "value": reps * sample * n_fft / t_cpu, "unit": "samples/s", "cores": 1,
+                    "kind": "reference" if po.ref_available() else "port",
+                    "sample": "%d x %d decimated outputs of buffer set 0, %d repetitions, cic_decimate of %s"
+                              % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
+                                 if po.ref_available() else "oracle/rtlws_oracle.c")}
+            else:
+                result["cpu_baseline"] = {
+                    "value": reps * sample / t_cpu, "unit": "spectra/s", "cores": cores, "kind": "port",
+                    "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
+                              "(oracle/rtlws_oracle.c) on %d pthreads" % (sample, frames, reps, cores)}
         print(json.dumps(result), flush=True)
 
     if dist is not None:

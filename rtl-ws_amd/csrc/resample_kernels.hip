@@ -16,12 +16,16 @@
 
 namespace rtlws {
 
-__global__ __launch_bounds__(256) void cic8_kernel(const uint4* __restrict__ src,
-                                                   int2* __restrict__ dst, long n)
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+typedef int nt_i2 __attribute__((ext_vector_type(2)));
+
+// Streamed once in, once out: nontemporal both ways.
+__global__ __launch_bounds__(256) void cic8_kernel(const nt_u4* __restrict__ src,
+                                                   nt_i2* __restrict__ dst, long n)
 {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += stride) {
-        const uint4 s = src[m];
+        const nt_u4 s = __builtin_nontemporal_load(src + m);
         unsigned si = 0, sq = 0;
         si = __builtin_amdgcn_udot4(s.x, 0x00010001u, si, false);
         sq = __builtin_amdgcn_udot4(s.x, 0x01000100u, sq, false);
@@ -31,7 +35,8 @@ __global__ __launch_bounds__(256) void cic8_kernel(const uint4* __restrict__ src
         sq = __builtin_amdgcn_udot4(s.z, 0x01000100u, sq, false);
         si = __builtin_amdgcn_udot4(s.w, 0x00010001u, si, false);
         sq = __builtin_amdgcn_udot4(s.w, 0x01000100u, sq, false);
-        dst[m] = make_int2((int)si - 8 * 128, (int)sq - 8 * 128);
+        const nt_i2 o = {(int)si - 8 * 128, (int)sq - 8 * 128};
+        __builtin_nontemporal_store(o, dst + m);
     }
 }
 
@@ -79,7 +84,7 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
         long blocks = (dst_len + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(cic8_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const uint4*>(d_src), reinterpret_cast<int2*>(d_dst),
+                           reinterpret_cast<const nt_u4*>(d_src), reinterpret_cast<nt_i2*>(d_dst),
                            dst_len);
     } else {
         long blocks = (dst_len + 255) / 256;

@@ -46,6 +46,52 @@ __global__ __launch_bounds__(64) void pat(const uint8_t* __restrict__ in, float*
     }
 }
 
+// FPI consecutive frames per wave-iteration (bigger contiguous bursts per wave); NT both
+template <int FPI>
+__global__ __launch_bounds__(64) void pat_burst(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    for (long f0 = (long)blockIdx.x * FPI; f0 < nframes; f0 += (long)gridDim.x * FPI) {
+        float acc[FPI][16];
+#pragma unroll
+        for (int j = 0; j < FPI; ++j) {
+            const uint16_t* src = reinterpret_cast<const uint16_t*>(in) + (f0 + j) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned v = __builtin_nontemporal_load(src + 64 * r + t);
+                acc[j][r] = (float)(v & 0xff) + (float)(v >> 8);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FPI; ++j) {
+            f4* dst = reinterpret_cast<f4*>(out + (f0 + j) * 1024);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f4 o = {acc[j][4 * s], acc[j][4 * s + 1], acc[j][4 * s + 2], acc[j][4 * s + 3]};
+                __builtin_nontemporal_store(o, dst + 64 * s + t);
+            }
+        }
+    }
+}
+
+template <int FPI>
+void run_burst(int waves_per_cu, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int blocks = 256 * waves_per_cu;
+    for (int i = 0; i < 10; ++i) pat_burst<FPI><<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipDeviceSynchronize());
+    const int steps = 200;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < steps; ++i) pat_burst<FPI><<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / steps;
+    printf("burst of %d frames per wave-iteration, NT       waves/CU %2d : %7.2f us  %6.0f GB/s\n", FPI, waves_per_cu, us, 6144.0 * nframes / us / 1e3);
+    fflush(stdout);
+}
+
 template <int LOADW, bool NTL, bool NTS, bool CONTIG>
 void run(const char* name, int waves_per_cu, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
 {
@@ -63,13 +109,69 @@ void run(const char* name, int waves_per_cu, std::vector<uint8_t*>& ins, std::ve
     fflush(stdout);
 }
 
+// one-direction and 1:1 ceilings with the same wave-per-2KiB-chunk structure
+template <int MODE, bool NT>   // 0 read-only (sum), 1 write-only, 2 copy 1:1 (4 KiB in, 4 KiB out)
+__global__ __launch_bounds__(64) void stream_k(const float* __restrict__ in, float* __restrict__ out, long nchunks)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    f4 acc = {0, 0, 0, 0};
+    for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {     // chunk = 4 KiB
+        const f4* src = reinterpret_cast<const f4*>(in) + c * 256;
+        f4* dst = reinterpret_cast<f4*>(out) + c * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f4 v = {1.0f, 2.0f, 3.0f, (float)c};
+            if (MODE != 1) v = NT ? __builtin_nontemporal_load(src + 64 * s + t) : src[64 * s + t];
+            if (MODE == 0) acc += v;
+            else if (NT) __builtin_nontemporal_store(v, dst + 64 * s + t);
+            else dst[64 * s + t] = v;
+        }
+    }
+    if (MODE == 0 && acc.x == 123.456f) out[t] = acc.y;
+}
+
+template <int MODE, bool NT>
+void run_stream(const char* name, float* a, float* b, long bytes_each)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const long nchunks = bytes_each / 4096;
+    for (int w : {8, 16, 32}) {
+        const int blocks = 256 * w;
+        stream_k<MODE, NT><<<blocks, 64>>>(a, b, nchunks);
+        CHECK(hipDeviceSynchronize());
+        const int steps = 100;
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < steps; ++i) stream_k<MODE, NT><<<blocks, 64>>>(a, b, nchunks);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / steps;
+        const double moved = (MODE == 2 ? 2.0 : 1.0) * bytes_each;
+        printf("%-30s waves/CU %2d : %8.2f us  %6.0f GB/s\n", name, w, us, moved / us / 1e3);
+    }
+    fflush(stdout);
+}
+
 int main()
 {
+    {
+        const long bytes = 1L << 30;      // 1 GiB each: far past the 256 MiB Infinity Cache
+        float *a, *b; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
+        CHECK(hipMemset(a, 0, bytes)); CHECK(hipMemset(b, 0, bytes));
+        run_stream<0, false>("read-only 1 GiB", a, b, bytes);
+        run_stream<0, true>("read-only 1 GiB NT", a, b, bytes);
+        run_stream<1, false>("write-only 1 GiB", a, b, bytes);
+        run_stream<1, true>("write-only 1 GiB NT", a, b, bytes);
+        run_stream<2, false>("copy 1 GiB -> 1 GiB", a, b, bytes);
+        run_stream<2, true>("copy 1 GiB -> 1 GiB NT", a, b, bytes);
+        CHECK(hipFree(a)); CHECK(hipFree(b));
+    }
     const long nframes = 65536;
     std::vector<uint8_t*> ins(4); std::vector<float*> outs(4);
     for (int i = 0; i < 4; ++i) { CHECK(hipMalloc(&ins[i], nframes * 2048)); CHECK(hipMalloc(&outs[i], nframes * 4096));
         CHECK(hipMemset(ins[i], 0x55 + i, nframes * 2048)); }
-    for (int w : {8, 12, 16, 24, 32}) {
+    for (int w : {4, 8, 16}) { run_burst<1>(w, ins, outs, nframes); run_burst<2>(w, ins, outs, nframes); run_burst<4>(w, ins, outs, nframes); }
+    for (int w : {8, 16}) {
         run<2, false, false, false>("u16 loads, plain, strided frames", w, ins, outs, nframes);
         run<16, false, false, false>("16B loads, plain, strided frames", w, ins, outs, nframes);
         run<2, false, true, false>("u16 loads, NT stores, strided", w, ins, outs, nframes);

@@ -21,6 +21,7 @@
  *                         optional src/cbb_main.c:121-130 dB/clamp epilogue
  *   rtlws_cic_block_sums  src/resample.c:21-40 (state handled by the caller)
  *   rtlws_halfband        src/resample.c:53-64
+ *   rtlws_fm_demod        src/audio_main.c:110-131, src/common_sp.h:40-76
  */
 #ifndef RTLWS_HIP_H
 #define RTLWS_HIP_H
@@ -132,6 +133,19 @@ int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src_cu8, long dst
  * has the 10 history samples in front: d_x holds 10 + 2*out_len floats and
  * x[i] here means d_x[10 + i].  Device pointers.  0 / -1 / -3. */
 int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, void* stream);
+
+/* FM-demodulator front end of the audio chain (reference src/audio_main.c:110-131
+ * with atan2_approx of src/common_sp.h:40-76):
+ *   phase_i = atan2_approx((float)im_i, (float)re_i)
+ *   out_i   = clamp(phase_i - phase_{i-1}, -1, 1),   phase_{-1} = *d_prev_in
+ * and *d_prev_out = phase_{len-1}.  d_iq: len cmplx_s32; all pointers device;
+ * d_prev_in and d_prev_out must differ.  Bit-identical to an IEEE evaluation
+ * of the reference's expressions.  0 / -1 / -3. */
+int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float* d_prev_in,
+                   float* d_prev_out, float* d_out, void* stream);
+
+/* Device-to-device copy on `stream` (delay-line upkeep of chained kernels). */
+int rtlws_copy_d2d(rtlws_engine* e, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 
 /* Bytes of LDS, VGPR count etc. are in DESIGN.md; this returns the grid the
  * fused kernel would launch for a descriptor and nframes (for tests). */

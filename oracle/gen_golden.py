@@ -14,6 +14,8 @@ Two kinds of vector, told apart by the `source` field in each file:
                           (delay-line carry) and a hand-set delay state
         rfdec_ref.npz     rf_decimator re-blocking with odd chunk sizes
         halfband_ref.npz  halfband_decimate, two consecutive calls
+        audio_ref.npz     audio_fm_demodulator (atan2_approx, difference, limiter,
+                          two half-bands): four consecutive decimator blocks
 
   source = "oracle_f64"
       Outputs of our own f64 restatement (src/spectrum.c and src/cbb_main.c
@@ -104,6 +106,28 @@ def gen_reference_vectors():
     np.savez_compressed(os.path.join(OUT, "halfband_ref.npz"), **d)
 
 
+def gen_audio_vectors():
+    """FM front end (src/audio_main.c + src/common_sp.h atan2_approx), reference
+    object code.  The reference keeps state in function statics: this must be
+    the only audio call of the process (it is)."""
+    rng = np.random.default_rng(20261004)
+    n = 2048 * 4
+    t = np.arange(n) / 204800.0
+    ph = 2 * np.pi * 40000 * np.cumsum(np.sin(2 * np.pi * 1000 * t)) / 204800.0
+    iq = np.stack([800 * np.cos(ph), 800 * np.sin(ph)], axis=1) + rng.normal(0, 30, size=(n, 2))
+    iq = np.round(iq).astype(np.int32)
+    # every branch of atan2_approx: x == 0 (y >, ==, < 0), the axes, all quadrants, |z| on both sides of 1
+    special = [(0, 7), (0, 0), (0, -3), (-5, 0), (5, 0), (3, 4), (-3, 4), (-3, -4), (3, -4),
+               (4, 3), (-4, 3), (-4, -3), (4, -3), (1, 1), (-1, 1), (-1, -1), (1, -1)]
+    for i, (re, im) in enumerate(special):
+        iq[40 + i] = (re, im)
+    blocks = [iq[i * 2048:(i + 1) * 2048] for i in range(4)]
+    audio = po.ref_audio_chain(blocks)
+    d = {"source": "reference_object_code", "iq": iq, "block_len": np.int32(2048),
+         "audio": np.stack(audio)}
+    np.savez_compressed(os.path.join(OUT, "audio_ref.npz"), **d)
+
+
 def gen_oracle_vectors():
     d = {"source": "oracle_f64"}
     iq = synth.tone_noise_iq(6, 1024, seed=11)
@@ -143,6 +167,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     po.build()
     gen_reference_vectors()
+    gen_audio_vectors()
     gen_oracle_vectors()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -58,6 +58,10 @@ def lib():
         L.orc_rfdec_resampled_len.argtypes = [vp]
         L.orc_rfdec_resampled_len.restype = i
         L.orc_rfdec_free.argtypes = [vp]
+        L.orc_atan2_approx.argtypes = [C.c_float, C.c_float]
+        L.orc_atan2_approx.restype = C.c_float
+        L.orc_fm_demod.argtypes = [vp, i, vp, vp]
+        L.orc_audio_block.argtypes = [vp, i, vp, vp]
         L.orc_spectrum_payload.argtypes = [i, vp, i, i, vp]
         L.orc_spectrum_payload.restype = i
         L.orc_estimate_spectrum.argtypes = [vp, i, vp]
@@ -166,6 +170,28 @@ def halfband_decimate(inp, delay):
     return out
 
 
+def atan2_approx(y, x):
+    return lib().orc_atan2_approx(float(y), float(x))
+
+
+def fm_demod(iq, prev_phase=0.0):
+    """iq int32 [len,2]; returns (demod f32[len], new prev_phase)."""
+    iq = np.ascontiguousarray(iq, dtype=np.int32).reshape(-1, 2)
+    out = np.empty(iq.shape[0], dtype=np.float32)
+    prev = np.array([prev_phase], dtype=np.float32)
+    lib().orc_fm_demod(_p(iq), iq.shape[0], _p(prev), _p(out))
+    return out, float(prev[0])
+
+
+def audio_block(iq, state):
+    """One decimator block through demod + 2 half-bands; state f32[21] updated in place."""
+    iq = np.ascontiguousarray(iq, dtype=np.int32).reshape(-1, 2)
+    assert state.dtype == np.float32 and state.size == 21
+    out = np.empty(iq.shape[0] // 4, dtype=np.float32)
+    lib().orc_audio_block(_p(iq), iq.shape[0], _p(state), _p(out))
+    return out
+
+
 _CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 
@@ -261,6 +287,10 @@ def ref():
         R.rf_decimator_decimate_cmplx_u8.argtypes = [vp, vp, i]
         R.rf_decimator_decimate_cmplx_u8.restype = i
         R.rf_decimator_free.argtypes = [vp]
+        R.audio_fm_demodulator.argtypes = [vp, i]
+        R.audio_get_audio_payload.argtypes = [vp, i]
+        R.audio_get_audio_payload.restype = i
+        R.audio_new_audio_available.restype = i
         _ref = R
     return _ref
 
@@ -305,3 +335,30 @@ def ref_rf_decimate(sample_rate, down_factor, chunks):
         rcs.append(R.rf_decimator_decimate_cmplx_u8(h, _p(ch), ch.shape[0]))
     R.rf_decimator_free(h)
     return rcs, blocks
+
+
+def ref_audio_chain(blocks):
+    """Feed int32 [len,2] blocks (all the same length) through the reference's
+    audio_fm_demodulator (src/audio_main.c, object code) in THIS process and
+    fetch the audio it queues, one buffer per read.  The reference keeps its
+    delay lines in function statics, so call this once per process
+    (oracle/gen_golden.py does, in a child process).
+
+    Two quirks of the reference's payload function (src/audio_main.c:40-72), which
+    is control plane and not part of the engine: it keeps using the buffer
+    pointer it peeked before popping, so the FIRST buffer is delivered twice;
+    and it offsets the char* destination by a sample count, so a read spanning
+    several buffers is garbage.  Hence: single-buffer reads, duplicate dropped."""
+    R = ref()
+    R.audio_init()
+    out = []
+    for k, b in enumerate(blocks):
+        b = np.ascontiguousarray(b, dtype=np.int32).reshape(-1, 2)
+        R.audio_fm_demodulator(_p(b), b.shape[0])
+        buf = np.zeros(b.shape[0] // 4, dtype=np.float32)
+        assert R.audio_get_audio_payload(_p(buf), buf.nbytes) == buf.nbytes
+        if k == 1:                       # the replay of the first buffer
+            assert np.array_equal(buf, out[0])
+            assert R.audio_get_audio_payload(_p(buf), buf.nbytes) == buf.nbytes
+        out.append(buf.copy())
+    return out

@@ -420,6 +420,60 @@ void orc_halfband_decimate(const float* input, float* output, int output_len, fl
 }
 
 /* ------------------------------------------------------------------ */
+/* audio front end: common_sp.h atan2_approx + audio_main.c demodulator */
+/* ------------------------------------------------------------------ */
+
+float orc_atan2_approx(float y, float x)
+{
+    const float pi_by_2 = (float)(M_PI / 2);                 /* src/common_sp.h:43 */
+    float at, z;
+    if (x == 0) {                                            /* :47-56 */
+        if (y > 0.0f) return pi_by_2;
+        if (y == 0) return 0;
+        return -pi_by_2;
+    }
+    z = y / x;                                               /* :57 */
+    if (fabs(z) < 1.0f) {                                    /* :58 */
+        at = z / (1.0f + 0.28f * z * z);                     /* :60 */
+        if (x < 0) {                                         /* :61-67: the +-M_PI is a double add */
+            if (y < 0.0f) return (float)((double)at - M_PI);
+            return (float)((double)at + M_PI);
+        }
+    } else {
+        at = pi_by_2 - z / (z * z + 0.28f);                  /* :71 */
+        if (y < 0.0f) return (float)((double)at - M_PI);     /* :72-73 */
+    }
+    return at;
+}
+
+void orc_fm_demod(const int32_t* iq, int len, float* prev_phase, float* out)
+{
+    float prev = *prev_phase;
+    int i;
+    for (i = 0; i < len; i++) {                              /* src/audio_main.c:110-131 */
+        const float ph = orc_atan2_approx((float)iq[2 * i + 1], (float)iq[2 * i]);
+        float d = ph - prev;
+        prev = ph;
+        if (d > 1.0f) d = 1;                                 /* hard limit, scale == 1 */
+        else if (d < -1.0f) d = -1;
+        else d = d / 1.0f;
+        out[i] = d;
+    }
+    *prev_phase = prev;
+}
+
+void orc_audio_block(const int32_t* iq, int len, float state[21], float* audio_out)
+{
+    float* demod = (float*)malloc(sizeof(float) * (size_t)(len > 0 ? len : 1));
+    float* work = (float*)malloc(sizeof(float) * (size_t)(len / 2 > 0 ? len / 2 : 1));
+    orc_fm_demod(iq, len, &state[0], demod);
+    orc_halfband_decimate(demod, work, len / 2, &state[1]);              /* src/audio_main.c:133 */
+    orc_halfband_decimate(work, audio_out, (len / 2) / 2, &state[11]);   /* :139 */
+    free(demod);
+    free(work);
+}
+
+/* ------------------------------------------------------------------ */
 /* rf_decimator.c                                                      */
 /* ------------------------------------------------------------------ */
 

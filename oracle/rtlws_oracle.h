@@ -13,13 +13,15 @@
  *   CIC              src/resample.c:6-45
  *   half-band        src/resample.c:4,47-67
  *   re-blocker       src/rf_decimator.c:53-119
+ *   FM front end     src/common_sp.h:40-76, src/audio_main.c:74-145 (next row §8f.3)
  *   dB payload       src/cbb_main.c:106-135
  *   frame harness    src/cbb_main.c:40-70 (blocks = min(len/1024, 6))
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - CIC, half-band, rf_decimator: pinned bit-exact against the reference's
- *     own object code (oracle/_ref, built from /root/reference/src/resample.c,
- *     rf_decimator.c, list.c) and against tests/golden/ fixtures made from it.
+ *   - CIC, half-band, rf_decimator, FM front end: pinned bit-exact against the
+ *     reference's own object code (oracle/_ref, built from /root/reference/src/
+ *     resample.c, rf_decimator.c, audio_main.c, list.c, rate_logger.c, common.c)
+ *     and against tests/golden/ fixtures made from it.
  *   - spectrum stage and dB payload: PARITY UNPINNED by reference execution.
  *     src/spectrum.c needs FFTW3 (un-vendored, unpinned "-lfftw3",
  *     Makefile:21) which is absent from this image (no header, no library),
@@ -86,6 +88,20 @@ int orc_cic_decimate(int R, const uint8_t* src_iq, int src_len, int32_t* dst_iq,
  * (compile this file with -ffp-contract=off to keep mul and add separate). */
 void orc_halfband_decimate(const float* input, float* output, int output_len,
                            float* delay10);
+
+/* ---- audio front end ---------------------------- */
+
+/* src/common_sp.h:40-76, f32 with the double-precision +-M_PI of the original. */
+float orc_atan2_approx(float y, float x);
+
+/* src/audio_main.c:110-131: phase = atan2_approx(im, re); out = phase - prev;
+ * hard limit to [-1, 1]; *prev carries the last phase across calls. */
+void orc_fm_demod(const int32_t* iq, int len, float* prev_phase, float* out);
+
+/* Whole chain of src/audio_main.c:74-145 for one decimator block of `len`
+ * samples: FM demod, half-band 2:1, half-band 2:1 -> len/4 audio samples.
+ * state = {prev_phase, delay1[10], delay2[10]} (21 floats, zero-initialised). */
+void orc_audio_block(const int32_t* iq, int len, float state[21], float* audio_out);
 
 /* ---- rf_decimator.c semantics --------------------------------------- */
 

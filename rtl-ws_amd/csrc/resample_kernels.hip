@@ -98,6 +98,70 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
     return hipGetLastError();
 }
 
+// atan2_approx of reference src/common_sp.h:40-76, evaluated as the C source
+// reads under IEEE rules: f32 divide/multiply/add without contraction (this
+// file is built with -ffp-contract=off), and the +-M_PI corrections as a
+// double-precision add rounded back to f32.
+__device__ __forceinline__ float atan2_approx_dev(float y, float x)
+{
+    const float pi_by_2 = (float)(3.14159265358979323846 / 2);
+    const double pi_d = 3.14159265358979323846;
+    if (x == 0.0f) {
+        if (y > 0.0f) return pi_by_2;
+        if (y == 0.0f) return 0.0f;
+        return -pi_by_2;
+    }
+    const float z = __fdiv_rn(y, x);
+    if (fabsf(z) < 1.0f) {
+        const float at = __fdiv_rn(z, __fadd_rn(1.0f, __fmul_rn(__fmul_rn(0.28f, z), z)));
+        if (x < 0.0f) {
+            if (y < 0.0f) return (float)((double)at - pi_d);
+            return (float)((double)at + pi_d);
+        }
+        return at;
+    }
+    const float at = __fsub_rn(pi_by_2, __fdiv_rn(z, __fadd_rn(__fmul_rn(z, z), 0.28f)));
+    if (y < 0.0f) return (float)((double)at - pi_d);
+    return at;
+}
+
+// reference src/audio_main.c:110-131: phase, first difference, hard limit.
+// Each thread recomputes its left neighbour's phase (elementwise, no scan).
+__global__ __launch_bounds__(256) void fm_demod_kernel(const int2* __restrict__ iq, long n,
+                                                       const float* __restrict__ prev_in,
+                                                       float* __restrict__ prev_out,
+                                                       float* __restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int2 s = iq[i];
+        const float ph = atan2_approx_dev((float)s.y, (float)s.x);
+        float pp;
+        if (i == 0) {
+            pp = *prev_in;
+        } else {
+            const int2 q = iq[i - 1];
+            pp = atan2_approx_dev((float)q.y, (float)q.x);
+        }
+        float d = __fsub_rn(ph, pp);
+        if (d > 1.0f) d = 1.0f;
+        else if (d < -1.0f) d = -1.0f;
+        out[i] = d;
+        if (i == n - 1) *prev_out = ph;
+    }
+}
+
+hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
+                           float* d_out, hipStream_t st)
+{
+    if (len <= 0) return hipSuccess;
+    long blocks = (len + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(fm_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const int2*>(d_iq), len, d_prev_in, d_prev_out, d_out);
+    return hipGetLastError();
+}
+
 // x points 10 floats into the buffer, so x[-10..-1] is the delay line
 // (reference src/resample.c:57,63: delay[(HALF_BAND_N - 1) + idx]).
 __global__ __launch_bounds__(256) void halfband_kernel(const float* __restrict__ xbuf,

@@ -405,6 +405,31 @@ int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len
     return 0;
 }
 
+int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_prev_in,
+                   float* d_prev_out, float* d_out, void* stream)
+{
+    g_err.clear();
+    if (!e || len < 0 || !d_prev_in || !d_prev_out || d_prev_in == d_prev_out ||
+        (len > 0 && (!d_iq || !d_out))) {
+        g_err = "rtlws_fm_demod: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_fm_demod(d_iq, len, d_prev_in, d_prev_out, d_out, pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("fm_demod kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+int rtlws_copy_d2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
+{
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick_stream(e, stream)), -3);
+    return 0;
+}
+
 int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, void* stream)
 {
     g_err.clear();

@@ -63,7 +63,10 @@ HIP_SYMBOLS = [
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
     "rtlws_event_elapsed_ms", "rtlws_event_sync", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
     "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
+    "rtlws_fm_demod", "rtlws_copy_d2d",
 ]
+AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
+                 "audio_fm_demodulator", "audio_close"]
 STREAM_SYMBOLS = ["rtlws_stream_open", "rtlws_stream_push", "rtlws_stream_flush",
                   "rtlws_stream_get_stats", "rtlws_stream_close"]
 AMD_SYMBOLS = [
@@ -125,6 +128,8 @@ def hip_lib():
         L.rtlws_cic_block_sums.argtypes = [vp, i, vp, l, vp, vp]
         L.rtlws_halfband.argtypes = [vp, vp, vp, l, vp]
         L.rtlws_payload_from_sums.argtypes = [vp, vp, i, i, i, vp, vp]
+        L.rtlws_fm_demod.argtypes = [vp, vp, l, vp, vp, vp, vp]
+        L.rtlws_copy_d2d.argtypes = [vp, vp, vp, sz, vp]
         L.rtlws_spectra_grid.argtypes = [vp, C.POINTER(SpectraDesc), l, C.POINTER(i),
                                          C.POINTER(i), C.POINTER(i)]
         _hip = L

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(built):
     for name in declared_hip:
         assert hasattr(hip, name), "librtlws_hip.so lacks " + name
     declared_amd = []
-    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h"):
+    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h", "audio_main.h"):
         fns = _declared_functions(h)
         assert fns, h
         declared_amd += fns
@@ -49,7 +49,7 @@ def test_every_declared_symbol_is_exported(built):
         assert hasattr(synth, name), "librtlws_synth.so lacks " + name
     # the binding's own lists agree with the headers
     assert set(built.HIP_SYMBOLS) == set(declared_hip)
-    assert set(built.AMD_SYMBOLS) | set(built.STREAM_SYMBOLS) == set(declared_amd)
+    assert set(built.AMD_SYMBOLS) | set(built.STREAM_SYMBOLS) | set(built.AUDIO_SYMBOLS) == set(declared_amd)
     assert set(built.CBB_SYMBOLS) == set(declared_cbb)
     assert set(built.SYNTH_SYMBOLS) == set(declared_synth)
 

@@ -230,3 +230,40 @@ def test_payload_goldens_and_estimate_blocks(oracle):
             want = g[f"{tag}_gain{gain}"]
             assert np.array_equal(oracle.spectrum_payload(ps, b, gain), want)
             assert want.size == (1024 if blocks else 0)
+
+
+# ---- FM audio front end: pinned to the reference's object code --
+
+def test_audio_golden_reference_object_code(oracle):
+    g = golden("audio_ref.npz")
+    assert str(g["source"]) == "reference_object_code"
+    n = int(g["block_len"])
+    st = np.zeros(21, dtype=np.float32)
+    for k in range(g["audio"].shape[0]):
+        out = oracle.audio_block(g["iq"][k * n:(k + 1) * n], st)
+        assert np.array_equal(out, g["audio"][k])              # bit-exact f32, state carried
+
+
+def test_atan2_approx_branches(oracle):
+    import math
+    # x == 0 (src/common_sp.h:47-56)
+    assert oracle.atan2_approx(3, 0) == np.float32(math.pi / 2)
+    assert oracle.atan2_approx(-3, 0) == -np.float32(math.pi / 2)
+    assert oracle.atan2_approx(0, 0) == 0.0
+    # within ~0.005 rad of atan2 everywhere else (it is an approximation)
+    rng = np.random.default_rng(1)
+    for y, x in rng.integers(-2000, 2000, size=(500, 2)):
+        if x == 0:
+            continue
+        a, b = oracle.atan2_approx(y, x), math.atan2(y, x)
+        err = abs(a - b)
+        assert min(err, abs(err - 2 * math.pi)) < 6e-3
+
+
+def test_fm_demod_difference_and_limit(oracle):
+    iq = np.array([[100, 0], [0, 100], [-100, 0], [100, 1], [100, 2]], dtype=np.int32)
+    out, prev = oracle.fm_demod(iq, prev_phase=0.0)
+    assert out[0] == 0.0
+    assert out[1] == 1.0 and out[2] == 1.0        # +pi/2 steps are limited to +1
+    assert out[3] == -1.0                         # the wrap from +pi to ~0 is limited to -1
+    assert abs(out[4] - 0.01) < 1e-3 and abs(prev - 0.02) < 1e-3

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 BUF_SAMPLES = 131072            # librtlsdr's default async buffer: 262144 bytes
 
 
-def _run(tmp_path, built, iq, fs=2400000, speedup=1.0, seconds=1.3, gains=(0,)):
+def _run(tmp_path, built, iq, fs=2400000, speedup=1.0, seconds=2.0, gains=(0,)):
     rec = tmp_path / "iq.u8"
     iq.tofile(rec)
     os.environ["RTLWS_SYNTH_FILE"] = str(rec)
@@ -56,7 +56,7 @@ def test_live_path_payload_and_cadence(tmp_path, built, oracle):
     iq = synth.tone_noise_iq(1, BUF_SAMPLES, seed=3).reshape(-1, 2)
     updates, payloads, seen = _run(tmp_path, built, iq, gains=(0, 15, -25))
     # 2.4 MS/s, 131072-sample buffers (54.6 ms), 250 ms gate -> every 5th buffer: ~3.7 Hz
-    assert 3 <= len(updates) <= 6
+    assert 3 <= len(updates) <= 9        # ~7 expected in 2 s; slack for a cold first launch
     if len(updates) >= 3:
         gaps = np.diff(updates)
         assert 0.2 < np.median(gaps) < 0.4

@@ -106,7 +106,9 @@ typedef struct rtlws_spectra_desc {
 
 /* d_in : nframes * n_fft * max(cic_r,1) input samples, device memory.
  * d_out: (nframes / k_avg) rows of n_fft outputs, device memory.
- * nframes must be a multiple of k_avg.  Asynchronous on `stream`.
+ * nframes must be a multiple of k_avg; d_in and d_out 16-byte aligned
+ * (any hipMalloc pointer, or one offset by whole frames / rows).
+ * Asynchronous on `stream`.
  * Returns 0; -1 bad descriptor/size; -3 HIP failure (see rtlws_last_error). */
 int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
                         long nframes, void* d_out, void* stream);

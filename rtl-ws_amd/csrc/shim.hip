@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -323,6 +324,12 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
         return -1;
     }
     if (nframes == 0) return 0;
+    // The kernels use 16-byte vector accesses (CIC input, N = 1024 output rows):
+    // refuse pointers the hardware would fault on rather than launch.
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || (reinterpret_cast<uintptr_t>(d_out) & 15u)) {
+        g_err = "rtlws_spectra_batch: d_in and d_out must be 16-byte aligned";
+        return -1;
+    }
     const bool fused = is_fused_n(d->n_fft);
     Tables tb;
     if (get_tables(e, d->n_fft, fused, &tb) != 0) return -3;
@@ -396,6 +403,10 @@ int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len
         g_err = "rtlws_cic_block_sums: bad argument (1 <= R <= 128)";
         return -1;
     }
+    if ((reinterpret_cast<uintptr_t>(d_src) & 15u) || (reinterpret_cast<uintptr_t>(d_dst) & 7u)) {
+        g_err = "rtlws_cic_block_sums: d_src must be 16-byte and d_dst 8-byte aligned";
+        return -1;
+    }
     HIP_TRY(hipSetDevice(e->device), -3);
     hipError_t err = rtlws::launch_cic_block_sums(R, d_src, dst_len, d_dst, pick_stream(e, stream));
     if (err != hipSuccess) {
@@ -412,6 +423,10 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_p
     if (!e || len < 0 || !d_prev_in || !d_prev_out || d_prev_in == d_prev_out ||
         (len > 0 && (!d_iq || !d_out))) {
         g_err = "rtlws_fm_demod: bad argument";
+        return -1;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 7u) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) {
+        g_err = "rtlws_fm_demod: d_iq must be 8-byte and d_out 4-byte aligned";
         return -1;
     }
     HIP_TRY(hipSetDevice(e->device), -3);

@@ -142,6 +142,9 @@ def test_bad_descriptors(engine, built):
     assert engine.spectra_batch(bad, d_in, 2, d_out, check=False) == -1
     ok = built.make_desc(1024)
     assert engine.spectra_batch(ok, d_in, 0, d_out, check=False) == 0       # empty batch
+    assert engine.spectra_batch(ok, d_in.ptr + 2, 1, d_out, check=False) == -1   # misaligned input
+    assert engine.spectra_batch(ok, d_in, 1, d_out.ptr + 4, check=False) == -1   # misaligned output
+    assert "aligned" in built.last_error()
 
 
 # ---- drop-in spectrum.h ------------------------------------------------------

@@ -138,3 +138,32 @@ def test_decimator_is_fed_by_cbb(tmp_path, built):
     stream = np.concatenate([iq] * 8)[: 204800]
     want = (stream.astype(np.int32) - 128).reshape(-1, 10, 2).sum(axis=1)
     assert np.array_equal(blocks[0], want)
+
+
+def test_reference_cbb_main_object_code_over_gpu_engine(tmp_path, built, oracle):
+    """Boundary #1 as the reference itself uses it: the reference's unmodified
+    src/cbb_main.c + src/signal_source.c (object code built by oracle/Makefile into
+    oracle/_ref/rtlws_ref_cbb_on_gpu) call spectrum_alloc / spectrum_add_cmplx_u8 /
+    rf_decimator_* of librtlws_amd.so through their own headers.  The payload's
+    dB arithmetic is the reference's f64 code; only the power sums are ours."""
+    import subprocess
+    from rtlws import synth
+    exe = os.path.join(os.path.dirname(built.ROOT), "oracle", "_ref", "rtlws_ref_cbb_on_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/rtlws_ref_cbb_on_gpu not built (needs /root/reference at build time)")
+    iq = synth.tone_noise_iq(1, BUF_SAMPLES, seed=8).reshape(-1, 2)
+    rec = tmp_path / "iq.u8"
+    iq.tofile(rec)
+    env = dict(os.environ, RTLWS_SYNTH_FILE=str(rec), RTLWS_SYNTH_SPEEDUP="1.0",
+               RTLWS_SYNTH_BUFLEN=str(2 * BUF_SAMPLES))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    ps, blocks = oracle.estimate_spectrum(iq[: 6 * 1024 + 10])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("gain ")]
+    assert len(lines) == 3
+    for line, gain in zip(lines, (0, 15, -25)):
+        parts = line.split()
+        assert int(parts[1]) == gain and int(parts[3]) == 1024
+        got = np.frombuffer(bytes.fromhex(parts[4]), dtype=np.uint8)
+        want = oracle.spectrum_payload(ps, 6, gain)
+        assert _near_integer_ok(got, want, ps, 6, gain)

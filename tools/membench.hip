@@ -46,6 +46,53 @@ __global__ __launch_bounds__(64) void pat(const uint8_t* __restrict__ in, float*
     }
 }
 
+// frame -> wave mappings: 0 strided (f = b + i*nb), 1 each XCD (b % 8) sweeps its own
+// contiguous eighth of the batch, 2 blocks of 8 consecutive frames rotate over XCDs
+template <int MAP>
+__global__ __launch_bounds__(64) void pat_map(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    const long nb = gridDim.x, b = blockIdx.x;
+    const long iters = nframes / nb;
+    for (long i = 0; i < iters; ++i) {
+        long f;
+        if (MAP == 0) f = b + i * nb;
+        else if (MAP == 1) f = (b % 8) * (nframes / 8) + (b / 8) + i * (nb / 8);
+        else f = ((b / 8) + i * (nb / 8)) * 8 + (b % 8);       // == MAP 0 reordered: sanity
+        float acc[16];
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(in) + f * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned v = __builtin_nontemporal_load(src + 64 * r + t);
+            acc[r] = (float)(v & 0xff) + (float)(v >> 8);
+        }
+        f4* dst = reinterpret_cast<f4*>(out + f * 1024);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f4 o = {acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};
+            __builtin_nontemporal_store(o, dst + 64 * s + t);
+        }
+    }
+}
+
+template <int MAP>
+void run_map(int waves_per_cu, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int blocks = 256 * waves_per_cu;
+    for (int i = 0; i < 10; ++i) pat_map<MAP><<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipDeviceSynchronize());
+    const int steps = 200;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < steps; ++i) pat_map<MAP><<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / steps;
+    printf("frame map %d, NT                                waves/CU %2d : %7.2f us  %6.0f GB/s\n", MAP, waves_per_cu, us, 6144.0 * nframes / us / 1e3);
+    fflush(stdout);
+}
+
 // FPI consecutive frames per wave-iteration (bigger contiguous bursts per wave); NT both
 template <int FPI>
 __global__ __launch_bounds__(64) void pat_burst(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
@@ -170,6 +217,7 @@ int main()
     std::vector<uint8_t*> ins(4); std::vector<float*> outs(4);
     for (int i = 0; i < 4; ++i) { CHECK(hipMalloc(&ins[i], nframes * 2048)); CHECK(hipMalloc(&outs[i], nframes * 4096));
         CHECK(hipMemset(ins[i], 0x55 + i, nframes * 2048)); }
+    for (int w : {8, 16}) { run_map<0>(w, ins, outs, nframes); run_map<1>(w, ins, outs, nframes); run_map<2>(w, ins, outs, nframes); }
     for (int w : {4, 8, 16}) { run_burst<1>(w, ins, outs, nframes); run_burst<2>(w, ins, outs, nframes); run_burst<4>(w, ins, outs, nframes); }
     for (int w : {8, 16}) {
         run<2, false, false, false>("u16 loads, plain, strided frames", w, ins, outs, nframes);

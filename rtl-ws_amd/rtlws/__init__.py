@@ -88,7 +88,17 @@ _amd = None
 _cbb = None
 
 
+_tried_build = False
+
+
 def _need(path):
+    """The product libraries are built in-tree (make -C rtl-ws_amd).  If one is
+    missing, build once (hipcc/gcc are on every box of this image); if it is
+    still missing, fail loudly -- there is no CPU implementation to fall back to."""
+    global _tried_build
+    if not os.path.exists(path) and not _tried_build and not os.environ.get("RTLWS_HIP_LIB"):
+        _tried_build = True
+        build()
     if not os.path.exists(path):
         raise RuntimeError(
             "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "

@@ -73,9 +73,15 @@ def init_distributed(torch, backend="nccl", device=None):
     barrier and the MAX-reduce of the elapsed time.  Returns (dist or None, world, rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world <= 1:
+    # under torch.distributed.run a 1-rank job still forms its group, so N = 1 and
+    # N > 1 go through the same code
+    if world <= 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         return None, 1, 0
     import torch.distributed as dist
+    # the contract is ONE line on stdout: keep RCCL's version banner (NCCL_DEBUG=VERSION
+    # prints it to stdout) out of it
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
     else:

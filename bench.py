@@ -78,10 +78,10 @@ def init_distributed(torch, backend="nccl", device=None):
     if world <= 1 and "TORCHELASTIC_RUN_ID" not in os.environ:
         return None, 1, 0
     import torch.distributed as dist
-    # the contract is ONE line on stdout: keep RCCL's version banner (NCCL_DEBUG=VERSION
-    # prints it to stdout) out of it
+    # the contract is ONE line on stdout: the box exports NCCL_DEBUG=VERSION, which makes
+    # RCCL print a version banner there; drop exactly that setting (anything else stays)
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
+        del os.environ["NCCL_DEBUG"]
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
     else:

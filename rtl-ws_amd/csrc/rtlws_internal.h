@@ -29,13 +29,21 @@ struct SpectraParams {
 };
 
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
-// second argument): N = 1024 fits 4 (121 VGPRs); the larger sizes carry R3 = 8
-// or 16 last-pass twiddles and a bigger last pass and spill at 128 VGPRs, so
-// they are built for 3 (<= 168 VGPRs).  RTLWS_WAVES_BIG overrides for experiments.
+// second argument), by instantiation.  N = 1024 fits 4 (120 VGPRs).  The larger
+// sizes carry R3 = 8 or 16 last-pass twiddles and a bigger last pass and spill at
+// 128 VGPRs, so they are built for 3 (<= 168 VGPRs) -- except the CIC-fused
+// K = 1 rectangular variant, which has no prefetch registers, fits 128 and is
+// latency-bound on its 16-byte loads, so it wants every wave it can get.
+// RTLWS_WAVES_BIG overrides the "3" for experiments.
 #ifndef RTLWS_WAVES_BIG
 #define RTLWS_WAVES_BIG 3
 #endif
-constexpr int fused_waves_per_simd(int n_fft) { return n_fft == 1024 ? 4 : RTLWS_WAVES_BIG; }
+constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
+{
+    return n_fft == 1024 ? 4
+           : (in_kind == IN_CU8_CIC8 && kone && !win && n_fft == 2048) ? 4
+           : RTLWS_WAVES_BIG;
+}
 
 // LDS the fused kernel needs, in float2 units: 16 (padded) rows + one spare slot
 // (layouts: spectrum_fused.hip, "LDS layouts").

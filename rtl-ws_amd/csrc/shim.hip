@@ -137,11 +137,12 @@ bool desc_ok(const rtlws_spectra_desc* d)
     return true;
 }
 
-int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups)
+int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0, bool win = false,
+                 bool kone = false)
 {
     // 4 x waves-per-SIMD wavefronts per CU, n_fft/1024 wavefronts per workgroup.
     // Persistent: each workgroup strides over the output rows.
-    int per_cu = 4 * rtlws::fused_waves_per_simd(n_fft) / (n_fft / 1024);
+    int per_cu = 4 * rtlws::fused_waves_per_simd(n_fft, in_kind, win, kone) / (n_fft / 1024);
     if (const char* ov = getenv("RTLWS_BLOCKS_PER_CU")) {   // experiments only
         const int v = atoi(ov);
         if (v > 0) per_cu = v;
@@ -304,7 +305,10 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
     if (!e || !desc_ok(d) || nframes < 0 || nframes % d->k_avg) return -1;
     const long ngroups = nframes / d->k_avg;
     if (is_fused_n(d->n_fft)) {
-        if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups);
+        int in_kind = d->input;
+        if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::IN_CU8_CICR;
+        if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
+                                           d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
         if (threads) *threads = d->n_fft / 16;
         if (lds_bytes) *lds_bytes = (int)(sizeof(float2) * rtlws::fused_lds_f2(d->n_fft));
     } else {
@@ -359,7 +363,8 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     hipStream_t st = pick_stream(e, stream);
     hipError_t err;
     if (fused) {
-        const int blocks = fused_blocks(e, d->n_fft, p.ngroups);
+        const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
+                                        d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
         switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
         case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;

@@ -33,10 +33,27 @@ while time.time() - t0 < budget_s:
     out = str(rng.choice(["power_sum", "power_sum", "mean_db", "payload_u8"]))
     gain = int(rng.choice([0, 15, -25, 40]))
     gen = [synth.tone_noise_iq, synth.uniform_iq, synth.pure_tone_iq][int(rng.integers(0, 3))]
-    iq = gen(rows * K, N * max(cic_r, 1), seed=int(rng.integers(0, 1 << 30)))
-    got = eng.spectra(iq, N, k_avg=K, window=window, output=out, cic_r=cic_r, gain_db=gain)
     w = None if window == "rect" else synth.hann(N)
-    if cic_r > 1:
+    kind = str(rng.choice(["cu8", "cu8", "cu8", "cs32", "rf32"]))
+    if kind != "cu8":                       # the s32 / real-f32 inputs of spectrum.h, row by row
+        cic_r, rows = 0, min(rows, 6)
+        if kind == "cs32":
+            data = rng.integers(-4000, 4000, size=(rows * K, N, 2), dtype=np.int32)
+        else:
+            data = rng.standard_normal((rows * K, N)).astype(np.float32)
+        got = eng.spectra(data, N, k_avg=K, input=kind, window=window, output=out, gain_db=gain)
+        ref = np.zeros((rows, N))
+        add = po.spectrum_add_cmplx_s32 if kind == "cs32" else po.spectrum_add_real_f32
+        for r in range(rows):
+            for k in range(K):
+                assert add(N, data[r * K + k], ref[r], window=w) == 0
+        gen = type("g", (), {"__name__": kind})
+    else:
+        iq = gen(rows * K, N * max(cic_r, 1), seed=int(rng.integers(0, 1 << 30)))
+        got = eng.spectra(iq, N, k_avg=K, window=window, output=out, cic_r=cic_r, gain_db=gain)
+    if kind != "cu8":
+        pass
+    elif cic_r > 1:
         ref = po.batch_spectra_cic_u8(iq, N, cic_r, K=K, window=w, nthreads=8)
     else:
         ref = po.batch_spectra_u8(iq, N, K=K, window=w, nthreads=8)

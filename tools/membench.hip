@@ -93,6 +93,43 @@ void run_map(int waves_per_cu, std::vector<uint8_t*>& ins, std::vector<float*>& 
     fflush(stdout);
 }
 
+// access pattern of a 32x32 decomposition with two frames per wavefront: lane (h, m) loads
+// x[32*r + m] of frame f+h (two 64-byte pieces per load instruction) and stores bin 32*p + m
+// (two 128-byte pieces per dword store instruction).
+__global__ __launch_bounds__(64) void pat_r32(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
+{
+    const int t = threadIdx.x, h = t >> 5, m = t & 31;
+    for (long f0 = (long)blockIdx.x * 2; f0 < nframes; f0 += (long)gridDim.x * 2) {
+        const long f = f0 + h;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(in) + f * 1024;
+        float acc[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            unsigned v = __builtin_nontemporal_load(src + 32 * r + m);
+            acc[r] = (float)(v & 0xff) + (float)(v >> 8);
+        }
+        float* dst = out + f * 1024;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) __builtin_nontemporal_store(acc[p], dst + 32 * p + m);
+    }
+}
+
+void run_r32(int waves_per_cu, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int blocks = 256 * waves_per_cu;
+    for (int i = 0; i < 10; ++i) pat_r32<<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipDeviceSynchronize());
+    const int steps = 200;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < steps; ++i) pat_r32<<<blocks, 64>>>(ins[i % ins.size()], outs[i % outs.size()], nframes);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / steps;
+    printf("32x32 pattern, 2 frames per wave, NT              waves/CU %2d : %7.2f us  %6.0f GB/s\n", waves_per_cu, us, 6144.0 * nframes / us / 1e3);
+    fflush(stdout);
+}
+
 // FPI consecutive frames per wave-iteration (bigger contiguous bursts per wave); NT both
 template <int FPI>
 __global__ __launch_bounds__(64) void pat_burst(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
@@ -217,6 +254,7 @@ int main()
     std::vector<uint8_t*> ins(4); std::vector<float*> outs(4);
     for (int i = 0; i < 4; ++i) { CHECK(hipMalloc(&ins[i], nframes * 2048)); CHECK(hipMalloc(&outs[i], nframes * 4096));
         CHECK(hipMemset(ins[i], 0x55 + i, nframes * 2048)); }
+    for (int w : {4, 8, 12, 16}) run_r32(w, ins, outs, nframes);
     for (int w : {8, 16}) { run_map<0>(w, ins, outs, nframes); run_map<1>(w, ins, outs, nframes); run_map<2>(w, ins, outs, nframes); }
     for (int w : {4, 8, 16}) { run_burst<1>(w, ins, outs, nframes); run_burst<2>(w, ins, outs, nframes); run_burst<4>(w, ins, outs, nframes); }
     for (int w : {8, 16}) {

@@ -47,6 +47,12 @@ rtlws_engine* rtlws_engine_create(int device);
 void rtlws_engine_destroy(rtlws_engine* e);
 int rtlws_engine_device(const rtlws_engine* e);
 
+/* Build the twiddle/window tables for an FFT size now (they are otherwise built
+ * on the first rtlws_spectra_batch call, which allocates and copies and is
+ * therefore not legal inside a hipGraph capture).  After this, batch launches
+ * for that size only enqueue a kernel and may be captured.  0 / -1 / -3. */
+int rtlws_engine_prepare(rtlws_engine* e, int n_fft);
+
 /* Last error text of the calling thread ("" when none). */
 const char* rtlws_last_error(void);
 

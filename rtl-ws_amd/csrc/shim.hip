@@ -203,6 +203,21 @@ void rtlws_engine_destroy(rtlws_engine* e)
 
 int rtlws_engine_device(const rtlws_engine* e) { return e ? e->device : -1; }
 
+int rtlws_engine_prepare(rtlws_engine* e, int n_fft)
+{
+    g_err.clear();
+    rtlws_spectra_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n_fft = n_fft;
+    d.k_avg = 1;
+    if (!e || !desc_ok(&d)) {
+        g_err = "rtlws_engine_prepare: unsupported size";
+        return -1;
+    }
+    Tables tb;
+    return get_tables(e, n_fft, is_fused_n(n_fft), &tb);
+}
+
 const char* rtlws_last_error(void) { return g_err.c_str(); }
 
 void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes)

@@ -1,0 +1,48 @@
+"""The batch launch is capturable into a hipGraph once the tables exist
+(rtlws_engine_prepare): ten launches captured with torch.cuda.graph on a side
+stream, replayed twice, results equal to eager launches and to the oracle."""
+import numpy as np
+import pytest
+
+from helpers import rel_err, EPS_K1, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_capture_and_replay(built, oracle):
+    import torch
+    from rtlws import synth
+    dev = torch.device("cuda", 0)
+    eng = built.Engine(0)
+    N, nframes, launches = 1024, 512, 10
+    assert built.hip_lib().rtlws_engine_prepare(eng.h, N) == 0
+    assert built.hip_lib().rtlws_engine_prepare(eng.h, 1) == -1
+    iq_host = synth.tone_noise_iq(nframes * launches, N, seed=9).reshape(launches, nframes, N, 2)
+    iq = torch.from_numpy(iq_host).to(dev)
+    out = torch.zeros((launches, nframes, N), dtype=torch.float32, device=dev)
+    desc = built.make_desc(N)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for i in range(launches):
+                eng.spectra_batch(desc, iq[i].data_ptr(), nframes, out[i].data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    assert float(out.abs().sum()) == 0.0            # capture enqueued nothing
+    g.replay()
+    torch.cuda.synchronize()
+    first = out.clone()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)                  # replays are bit-identical
+    ref = oracle.batch_spectra_u8(iq_host[3], N, nthreads=8)
+    assert rel_err(out[3].cpu().numpy(), ref, EPS_K1).max() <= TOL
+    eager = torch.zeros((nframes, N), dtype=torch.float32, device=dev)
+    eng.spectra_batch(desc, iq[3].data_ptr(), nframes, eager.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, out[3])
+    eng.close()

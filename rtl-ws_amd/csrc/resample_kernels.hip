@@ -41,34 +41,60 @@ __global__ __launch_bounds__(256) void cic8_kernel(const nt_u4* __restrict__ src
 }
 
 // Any R >= 1.  One wavefront owns 64 consecutive outputs = 64*R consecutive
-// input samples, reads them with coalesced 2-byte loads into LDS and then
-// each lane sums its own R samples from LDS (stride R halfwords: odd R is
-// conflict-free, even R costs a few-way conflict on a path that is not the
-// headline).
-__global__ __launch_bounds__(256) void cicr_kernel(const uint16_t* __restrict__ src,
-                                                   int2* __restrict__ dst, long n, int R)
+// input samples = 128*R contiguous bytes.  They are staged through LDS with
+// coalesced 16-byte loads / ds_write_b128; then each lane sums its own R samples:
+// even R reads them as R/2 dwords (lane stride R/2 dwords: conflict-free for
+// R = 2 mod 4 such as the product's R = 10, rotated per lane otherwise) and reduces
+// with v_dot4_u32_u8 like the R = 8 kernel; odd R reads halfwords.
+__global__ __launch_bounds__(256) void cicr_kernel(const uint8_t* __restrict__ src,
+                                                   nt_i2* __restrict__ dst, long n, int R)
 {
-    extern __shared__ uint16_t stage[];           // 4 waves * 64 * R halfwords
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];   // 4 waves * 128 * R bytes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint16_t* my = stage + (size_t)wave * 64 * R;
+    uint8_t* my = stage + (size_t)wave * 128 * R;
     const long wave_stride = (long)gridDim.x * 4;
     for (long w = (long)blockIdx.x * 4 + wave; w * 64 < n; w += wave_stride) {
         const long m0 = w * 64;
-        const long navail = (n - m0 < 64 ? n - m0 : 64) * (long)R;   // samples this wave owns
-        const uint16_t* base = src + m0 * R;
-        for (long i = lane; i < navail; i += 64) my[i] = base[i];
+        const long nbytes = (n - m0 < 64 ? n - m0 : 64) * 2L * R;    // bytes this wave owns
+        const uint8_t* base = src + m0 * 2L * R;                      // 128*R*w: 16-byte aligned
+        for (long off = (long)lane * 16; off < nbytes; off += 1024) {
+            if (off + 16 <= nbytes) {
+                *reinterpret_cast<nt_u4*>(my + off) =
+                    __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(base + off));
+            } else {                                                   // ragged tail of the last wave
+                for (long b = off; b < nbytes; b += 2)
+                    *reinterpret_cast<uint16_t*>(my + b) = *reinterpret_cast<const uint16_t*>(base + b);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (m0 + lane < n) {
-            int si = 0, sq = 0;
-            const uint16_t* q = my + (size_t)lane * R;
-            for (int i = 0; i < R; ++i) {
-                const unsigned s = q[i];
-                si += (int)(s & 0xffu);
-                sq += (int)(s >> 8);
+            unsigned si = 0, sq = 0;
+            const uint8_t* q = my + (size_t)lane * 2 * R;
+            if ((R & 1) == 0) {
+                const unsigned* qd = reinterpret_cast<const unsigned*>(q);
+                // lane stride is S = R/2 dwords; when S shares a factor with the 32
+                // banks, start each lane's (order-free) sum at a different dword so
+                // that a 32-lane group still spreads over all banks
+                const int S = R / 2;
+                int idx = (S & 1) ? 0 : (lane * S / 32) % S;
+                for (int i = 0; i < S; ++i) {
+                    const unsigned d = qd[idx];
+                    if (++idx == S) idx = 0;
+                    si = __builtin_amdgcn_udot4(d, 0x00010001u, si, false);
+                    sq = __builtin_amdgcn_udot4(d, 0x01000100u, sq, false);
+                }
+            } else {
+                const uint16_t* qh = reinterpret_cast<const uint16_t*>(q);
+                for (int i = 0; i < R; ++i) {
+                    const unsigned s = qh[i];
+                    si += s & 0xffu;
+                    sq += s >> 8;
+                }
             }
-            dst[m0 + lane] = make_int2(si - 128 * R, sq - 128 * R);
+            const nt_i2 o = {(int)si - 128 * R, (int)sq - 128 * R};
+            __builtin_nontemporal_store(o, dst + m0 + lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -89,11 +115,11 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
     } else {
         long blocks = (dst_len + 255) / 256;
         if (blocks > 256 * 4) blocks = 256 * 4;
-        const size_t lds = sizeof(uint16_t) * 4 * 64 * (size_t)R;
+        const size_t lds = (size_t)4 * 128 * (size_t)R;
         if (lds > 64 * 1024) return hipErrorInvalidValue;   // R <= 128
         hipLaunchKernelGGL(cicr_kernel, dim3((unsigned)blocks), dim3(256), lds, st,
-                           reinterpret_cast<const uint16_t*>(d_src),
-                           reinterpret_cast<int2*>(d_dst), dst_len, R);
+                           reinterpret_cast<const uint8_t*>(d_src),
+                           reinterpret_cast<nt_i2*>(d_dst), dst_len, R);
     }
     return hipGetLastError();
 }

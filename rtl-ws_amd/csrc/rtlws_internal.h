@@ -8,8 +8,13 @@
 namespace rtlws {
 
 // Input kinds as the kernels see them (the public enum rtlws_input plus the
-// two CIC-fused variants selected from rtlws_spectra_desc::cic_r).
-enum { IN_CU8 = 0, IN_CS32 = 1, IN_RF32 = 2, IN_CU8_CIC8 = 3, IN_CU8_CICR = 4 };
+// CIC-fused variants selected from rtlws_spectra_desc::cic_r).
+// (IN_CU8_CICRw: generic R read w bytes at a time; keep them last and in this order)
+enum { IN_CU8 = 0, IN_CS32 = 1, IN_RF32 = 2, IN_CU8_CIC8 = 3,
+       IN_CU8_CICR2 = 4, IN_CU8_CICR4 = 5, IN_CU8_CICR8 = 6, IN_CU8_CICR16 = 7 };
+
+// generic-R CIC input kind by the alignment of a 2R-byte decimated sample
+constexpr int cicr_kind(int R) { return (R % 8 == 0) ? IN_CU8_CICR16 : (R % 4 == 0) ? IN_CU8_CICR8 : (R % 2 == 0) ? IN_CU8_CICR4 : IN_CU8_CICR2; }
 enum { OUT_SUM = 0, OUT_DB = 1, OUT_PAYLOAD = 2 };
 
 struct SpectraParams {
@@ -32,8 +37,8 @@ struct SpectraParams {
 // second argument), by instantiation.  N = 1024 fits 4 (120 VGPRs).  The larger
 // sizes carry R3 = 8 or 16 last-pass twiddles and a bigger last pass and spill at
 // 128 VGPRs, so they are built for 3 (<= 168 VGPRs) -- except the CIC-fused
-// K = 1 rectangular variant, which has no prefetch registers, fits 128 and is
-// latency-bound on its 16-byte loads, so it wants every wave it can get.
+// rectangular 2048-point variants, which have no prefetch registers, fit 128 and
+// are latency-bound on their loads, so they want every wave they can get.
 // RTLWS_WAVES_BIG overrides the "3" for experiments.
 #ifndef RTLWS_WAVES_BIG
 #define RTLWS_WAVES_BIG 3
@@ -41,7 +46,7 @@ struct SpectraParams {
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
     return n_fft == 1024 ? 4
-           : (in_kind == IN_CU8_CIC8 && kone && !win && n_fft == 2048) ? 4
+           : (in_kind >= IN_CU8_CIC8 && !win && n_fft == 2048) ? 4
            : RTLWS_WAVES_BIG;
 }
 

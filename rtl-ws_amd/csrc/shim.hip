@@ -321,7 +321,7 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
     const long ngroups = nframes / d->k_avg;
     if (is_fused_n(d->n_fft)) {
         int in_kind = d->input;
-        if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::IN_CU8_CICR;
+        if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::cicr_kind(d->cic_r);
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
                                            d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
         if (threads) *threads = d->n_fft / 16;
@@ -372,7 +372,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     p.lin_gain = (float)(std::pow(10.0, (double)(d->gain_db / 10)) / (double)d->k_avg);
 
     int in_kind = d->input;
-    if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::IN_CU8_CICR;
+    if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::cicr_kind(d->cic_r);
 
     HIP_TRY(hipSetDevice(e->device), -3);
     hipStream_t st = pick_stream(e, stream);
@@ -386,7 +386,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
         default: err = rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st); break;
         }
     } else {
-        if (in_kind == rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8_CICR;
+        if (in_kind >= rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8;     // the direct kernel sums R bytes itself
         err = rtlws::launch_spectra_direct(p, in_kind, st);
     }
     if (err != hipSuccess) {

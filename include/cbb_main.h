@@ -21,6 +21,8 @@
  * every 250 ms, the first min(len/1024, 6) frames of the buffer become ONE
  * launch of the fused kernel (K = blocks); the 1024 f32 sums stay on the
  * device and the dB/clamp conversion is a second small kernel at payload time.
+ * With RTLWS_CBB_ALL_FRAMES=1 in the environment at cbb_init, every whole frame
+ * of the buffer is averaged instead of the first 6 (same payload format).
  */
 #ifndef CBB_MAIN_H
 #define CBB_MAIN_H

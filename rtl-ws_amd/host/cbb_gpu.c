@@ -43,6 +43,8 @@ static int g_pub_count = 0;             /* frames behind g_d_pub */
 static uint64_t g_last_est_ms = 0;
 static volatile int g_new_spectrum = 0;
 static uint64_t g_samples_seen = 0;
+static int g_max_blocks = FFT_AVERAGE;  /* RTLWS_CBB_ALL_FRAMES=1: every frame of the buffer */
+#define MAX_BLOCKS_ALL 1024             /* device staging bound for that mode (2 MiB of IQ)  */
 
 static uint64_t now_ms(void)
 {
@@ -72,7 +74,7 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
     rtlws_spectra_desc d;
 
     if (now_ms() < g_last_est_ms + SPECTRUM_EST_MS) return;      /* :46-47 */
-    blocks = blocks <= FFT_AVERAGE ? blocks : FFT_AVERAGE;        /* :49 */
+    blocks = blocks <= g_max_blocks ? blocks : g_max_blocks;     /* :49 (6 unless ALL_FRAMES) */
 
     pthread_mutex_lock(&g_mu);
     if (blocks > 0) {
@@ -116,11 +118,17 @@ void cbb_init(int decimated_bw_target_hz)
         fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
         abort();                                /* no CPU path to fall back to */
     }
-    g_d_iq = rtlws_dev_alloc(g_eng, (size_t)FFT_AVERAGE * FFT_POINTS * sizeof(cmplx_u8));
+    {   /* the reference transforms 6 of the ~128 frames a sensor
+         * buffer carries (:46-49); with RTLWS_CBB_ALL_FRAMES=1 the same launch averages
+         * all of them (K = len/1024) -- same payload format, smoother spectrum */
+        const char* all = getenv("RTLWS_CBB_ALL_FRAMES");
+        g_max_blocks = (all && atoi(all) > 0) ? MAX_BLOCKS_ALL : FFT_AVERAGE;
+    }
+    g_d_iq = rtlws_dev_alloc(g_eng, (size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
     g_d_work = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
     g_d_pub = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
     g_d_payload = rtlws_dev_alloc(g_eng, FFT_POINTS);
-    g_h_iq = (cmplx_u8*)rtlws_pinned_alloc((size_t)FFT_AVERAGE * FFT_POINTS * sizeof(cmplx_u8));
+    g_h_iq = (cmplx_u8*)rtlws_pinned_alloc((size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
     g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
     if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_h_iq || !g_h_payload) {
         fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());

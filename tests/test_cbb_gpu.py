@@ -167,3 +167,20 @@ def test_reference_cbb_main_object_code_over_gpu_engine(tmp_path, built, oracle)
         got = np.frombuffer(bytes.fromhex(parts[4]), dtype=np.uint8)
         want = oracle.spectrum_payload(ps, 6, gain)
         assert _near_integer_ok(got, want, ps, 6, gain)
+
+
+def test_all_frames_mode(tmp_path, built, oracle):
+    """RTLWS_CBB_ALL_FRAMES=1: all 128 frames of a sensor buffer in
+    one launch, payload format unchanged."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(1, BUF_SAMPLES, seed=6).reshape(-1, 2)
+    os.environ["RTLWS_CBB_ALL_FRAMES"] = "1"
+    try:
+        updates, payloads, _ = _run(tmp_path, built, iq, seconds=1.0, gains=(0,))
+    finally:
+        os.environ.pop("RTLWS_CBB_ALL_FRAMES", None)
+    assert len(updates) >= 2
+    ref = oracle.batch_spectra_u8(iq, 1024, K=128, nthreads=8)[0]
+    want = oracle.spectrum_payload(ref, 128, 0)
+    for (got,) in payloads:
+        assert got.size == 1024 and _near_integer_ok(got, want, ref, 128, 0)

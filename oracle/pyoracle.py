@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RTLWS_ORACLE_LIB: an alternative build of the same source (e.g. with sanitizers, tools/asan_cpu.sh)
+# RTLWS_ORACLE_LIB: an alternative build of the same source (e.g. with sanitizers, tests/tools/asan_cpu.sh)
 _LIB_PATH = os.environ.get("RTLWS_ORACLE_LIB") or os.path.join(_HERE, "librtlws_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "librtlws_ref.so")
 

@@ -10,11 +10,33 @@ namespace rtlws {
 // Input kinds as the kernels see them (the public enum rtlws_input plus the
 // CIC-fused variants selected from rtlws_spectra_desc::cic_r).
 // (IN_CU8_CICRw: generic R read w bytes at a time; keep them last and in this order)
+// IN_CU8_CICR_LDSg: input staged through LDS by global_load_lds (whole
+// 128-byte lines whatever R is), g of a wavefront's sixteen 64-sample pieces at
+// a time.
 enum { IN_CU8 = 0, IN_CS32 = 1, IN_RF32 = 2, IN_CU8_CIC8 = 3,
-       IN_CU8_CICR2 = 4, IN_CU8_CICR4 = 5, IN_CU8_CICR8 = 6, IN_CU8_CICR16 = 7 };
+       IN_CU8_CICR2 = 4, IN_CU8_CICR4 = 5, IN_CU8_CICR8 = 6, IN_CU8_CICR16 = 7,
+       IN_CU8_CICR_LDS4 = 8, IN_CU8_CICR_LDS2 = 9, IN_CU8_CICR_LDS1 = 10 };
 
-// generic-R CIC input kind by the alignment of a 2R-byte decimated sample
-constexpr int cicr_kind(int R) { return (R % 8 == 0) ? IN_CU8_CICR16 : (R % 4 == 0) ? IN_CU8_CICR8 : (R % 2 == 0) ? IN_CU8_CICR4 : IN_CU8_CICR2; }
+// LDS staging of the CIC-fused input: each wavefront owns CICR_LDS_WAVE_BYTES of
+// the transposition buffer (fused_lds_f2 gives >= 9216 B per wavefront at every
+// N); a piece (64 samples) is 128R bytes.
+constexpr int CICR_LDS_WAVE_BYTES = 9216;
+constexpr int cicr_lds_round(int in_kind) { return in_kind == IN_CU8_CICR_LDS4 ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
+constexpr int cicr_lds_max_r(int round) { return CICR_LDS_WAVE_BYTES / (round * 128); }   // 18, 36, 72
+
+// generic-R CIC input kind: per-lane direct loads by the alignment of a 2R-byte
+// decimated sample, or LDS staging (3 <= R <= 72; measured 1.2-5x faster than
+// the direct loads there, slower at R = 2: tools/cic_fused_rates.py)
+constexpr int cicr_direct_kind(int R) { return (R % 8 == 0) ? IN_CU8_CICR16 : (R % 4 == 0) ? IN_CU8_CICR8 : (R % 2 == 0) ? IN_CU8_CICR4 : IN_CU8_CICR2; }
+constexpr int cicr_lds_kind(int R, int round)   // -1: does not fit
+{
+    return (R < 2 || R > cicr_lds_max_r(round)) ? -1 : round == 4 ? IN_CU8_CICR_LDS4 : round == 2 ? IN_CU8_CICR_LDS2 : IN_CU8_CICR_LDS1;
+}
+constexpr int cicr_kind(int R)
+{
+    if (R < 3 || R > cicr_lds_max_r(1)) return cicr_direct_kind(R);
+    return R <= cicr_lds_max_r(4) ? IN_CU8_CICR_LDS4 : R <= cicr_lds_max_r(2) ? IN_CU8_CICR_LDS2 : IN_CU8_CICR_LDS1;
+}
 enum { OUT_SUM = 0, OUT_DB = 1, OUT_PAYLOAD = 2 };
 
 struct SpectraParams {

@@ -308,6 +308,27 @@ float rtlws_event_elapsed_ms(void* start, void* stop)
     return ms;
 }
 
+// Input stage of the fused kernel for a CIC factor.  For A/B experiments
+// (tools/cic_fused_rates.py): RTLWS_CIC_DIRECT=1 keeps every R != 8 on the
+// per-lane direct loads, RTLWS_CIC_ROUND=1|2|4 forces the LDS staging depth
+// where R fits it.
+static int cic_in_kind(int R)
+{
+    if (R == 8) return rtlws::IN_CU8_CIC8;
+    static const int force = [] {
+        const char* v = getenv("RTLWS_CIC_DIRECT");
+        if (v && v[0] == '1') return -1;
+        v = getenv("RTLWS_CIC_ROUND");
+        return v ? atoi(v) : 0;
+    }();
+    if (force < 0) return rtlws::cicr_direct_kind(R);
+    if (force == 1 || force == 2 || force == 4) {
+        const int k = rtlws::cicr_lds_kind(R, force);
+        if (k >= 0) return k;
+    }
+    return rtlws::cicr_kind(R);
+}
+
 int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* d)
 {
     if (!desc_ok(d)) return 0;
@@ -321,7 +342,7 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
     const long ngroups = nframes / d->k_avg;
     if (is_fused_n(d->n_fft)) {
         int in_kind = d->input;
-        if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::cicr_kind(d->cic_r);
+        if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
                                            d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
         if (threads) *threads = d->n_fft / 16;
@@ -372,7 +393,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     p.lin_gain = (float)(std::pow(10.0, (double)(d->gain_db / 10)) / (double)d->k_avg);
 
     int in_kind = d->input;
-    if (d->cic_r > 1) in_kind = (d->cic_r == 8) ? rtlws::IN_CU8_CIC8 : rtlws::cicr_kind(d->cic_r);
+    if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
 
     HIP_TRY(hipSetDevice(e->device), -3);
     hipStream_t st = pick_stream(e, stream);

@@ -81,6 +81,22 @@ def test_cic_fused(engine, oracle, R):
     assert rel_err(got, ref, EPS_K1).max() <= TOL
 
 
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("R", [2, 3, 5, 6, 9, 10, 12, 15, 16, 18, 19, 20, 32, 36, 37, 40, 64, 71, 72, 73, 74])
+def test_cic_fused_every_input_stage(engine, oracle, N, R):
+    """3 <= R <= 72 are staged through LDS (global_load_lds; 4, 2 or 1 pieces
+    per round by size; odd R with a half-wavefront tail piece and masked half
+    dwords), the rest read
+    per lane; K = 3 makes every workgroup run the stage again right after the
+    previous frame's last pass (the LDS slice is shared with the transform)."""
+    rng = np.random.default_rng(100 * R + N // 1024)
+    iq = rng.integers(0, 256, size=(6, N * R, 2), dtype=np.uint8)
+    ref1 = oracle.batch_spectra_cic_u8(iq, N, R)
+    assert rel_err(engine.spectra(iq, N, cic_r=R), ref1, EPS_K1).max() <= TOL
+    ref3 = oracle.batch_spectra_cic_u8(iq, N, R, K=3)
+    assert rel_err(engine.spectra(iq, N, cic_r=R, k_avg=3), ref3, EPS_K1).max() <= TOL
+
+
 def test_s32_and_f32_inputs(engine, oracle):
     rng = np.random.default_rng(8)
     N = 1024

@@ -29,7 +29,7 @@ while time.time() - t0 < budget_s:
     K = int(rng.choice([1, 1, 2, 3, 6, 8, 17]))
     rows = int(rng.integers(1, 40 if fused else 4))
     window = str(rng.choice(["rect", "rect", "hann"]))
-    cic_r = int(rng.choice([0, 0, 0, 2, 5, 8, 8, 12])) if fused else int(rng.choice([0, 3]))
+    cic_r = int(rng.choice([0, 0, 0, 2, 5, 8, 8, 12, 10, 7, 16, 24, 48])) if fused else int(rng.choice([0, 3]))
     out = str(rng.choice(["power_sum", "power_sum", "mean_db", "payload_u8"]))
     gain = int(rng.choice([0, 15, -25, 40]))
     gen = [synth.tone_noise_iq, synth.uniform_iq, synth.pure_tone_iq][int(rng.integers(0, 3))]

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Fused CIC + 2048-pt spectrum rates for several R (device-resident)."""
+"""Fused CIC + N-pt spectrum rates for several R (device-resident).
+
+    python tools/cic_fused_rates.py [N] [R ...]
+
+RTLWS_CIC_DIRECT=1 in the environment keeps R != 8 on the per-lane loads
+(A/B against the LDS-staged input stage; run both in one gpurun call)."""
 import os
 import sys
 
@@ -15,9 +20,11 @@ dev = torch.device("cuda", 0)
 eng = rtlws.Engine(0)
 L = rtlws.hip_lib()
 stream = torch.cuda.current_stream().cuda_stream
-N = 2048
-for R in (8, 10, 12, 5, 16):
-    nspec = 8192 * 8 // R
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+RS = [int(a) for a in sys.argv[2:]] or [8, 10, 12, 5, 16]
+print('N=%d  RTLWS_CIC_DIRECT=%s' % (N, os.environ.get('RTLWS_CIC_DIRECT', '0')))
+for R in RS:
+    nspec = 8192 * 8 * 2048 // (R * N)
     desc = rtlws.make_desc(N, cic_r=R)
     src = [torch.randint(0, 256, (nspec, N * R, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
     dst = [torch.empty((nspec, N), dtype=torch.float32, device=dev) for _ in range(3)]

@@ -35,6 +35,8 @@ WORKLOADS = {
     "batched_1024pt_64k_frames": (1024, 1, "rect", "power_sum", 0, 65536),
     "hann_4096pt_k8_db": (4096, 8, "hann", "mean_db", 0, 16384),
     "cic8_2048pt": (2048, 1, "rect", "power_sum", 8, 8192),
+    # the reference's own factor at BASELINE's 2.4 MS/s (src/main.c:23,154: 2.4e6 / 192e3 = 12)
+    "cic12_2048pt": (2048, 1, "rect", "power_sum", 12, 5456),
     # stand-alone CIC (reference src/resample.c:6-45): "frame" = 2048 decimated outputs,
     # 2*8*2048 bytes in, 8*2048 bytes out; unit reported: decimated samples/s
     "cic8_block_sums": (2048, 1, "rect", "cs32", 8, 8192),

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "rtlws_internal.h"
+#include "cic_lds.h"
 
 namespace rtlws {
 
@@ -40,65 +41,45 @@ __global__ __launch_bounds__(256) void cic8_kernel(const nt_u4* __restrict__ src
     }
 }
 
-// Any R >= 1.  One wavefront owns 64 consecutive outputs = 64*R consecutive
-// input samples = 128*R contiguous bytes.  They are staged through LDS with
-// coalesced 16-byte loads / ds_write_b128; then each lane sums its own R samples:
-// even R reads them as R/2 dwords (lane stride R/2 dwords: conflict-free for
-// R = 2 mod 4 such as the product's R = 10, rotated per lane otherwise) and reduces
-// with v_dot4_u32_u8 like the R = 8 kernel; odd R reads halfwords.
+// Any 1 <= R <= 128, staged through LDS (cic_lds.h).  One wavefront owns rounds
+// of G consecutive pieces (a piece = 64 outputs = 128R contiguous input bytes),
+// all G copies in flight together, then one 8-byte nontemporal store per lane
+// and piece.  The < 64 outputs that do not fill a piece are summed straight from
+// global memory by one wavefront.
 __global__ __launch_bounds__(256) void cicr_kernel(const uint8_t* __restrict__ src,
-                                                   nt_i2* __restrict__ dst, long n, int R)
+                                                   nt_i2* __restrict__ dst, long n, int R,
+                                                   int slice_bytes, int G)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];   // 4 waves * 128 * R bytes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* my = stage + (size_t)wave * 128 * R;
-    const long wave_stride = (long)gridDim.x * 4;
-    for (long w = (long)blockIdx.x * 4 + wave; w * 64 < n; w += wave_stride) {
-        const long m0 = w * 64;
-        const long nbytes = (n - m0 < 64 ? n - m0 : 64) * 2L * R;    // bytes this wave owns
-        const uint8_t* base = src + m0 * 2L * R;                      // 128*R*w: 16-byte aligned
-        for (long off = (long)lane * 16; off < nbytes; off += 1024) {
-            if (off + 16 <= nbytes) {
-                *reinterpret_cast<nt_u4*>(my + off) =
-                    __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(base + off));
-            } else {                                                   // ragged tail of the last wave
-                for (long b = off; b < nbytes; b += 2)
-                    *reinterpret_cast<uint16_t*>(my + b) = *reinterpret_cast<const uint16_t*>(base + b);
-            }
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];   // 4 wavefronts * slice_bytes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    uint8_t* my = stage + wave * slice_bytes;
+    const int chunk = 128 * R;
+    const long npieces = n / 64;
+    const long round_stride = (long)gridDim.x * 4 * G;
+    const CicLaneSum ls = cic_lane_setup(R, lane);
+    for (long p0 = ((long)blockIdx.x * 4 + wave) * G; p0 < npieces; p0 += round_stride) {
+        const int gn = (npieces - p0 < G) ? (int)(npieces - p0) : G;
+        for (int g = 0; g < gn; ++g) cic_piece_to_lds(src + (p0 + g) * chunk, my + g * chunk, R, lane);
+        cic_wait_pieces();
+        for (int g = 0; g < gn; ++g) {
+            const int2 sum = cic_lane_sum(my + g * chunk, ls);
+            const nt_i2 o = {sum.x, sum.y};
+            __builtin_nontemporal_store(o, dst + (p0 + g) * 64 + lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (m0 + lane < n) {
-            unsigned si = 0, sq = 0;
-            const uint8_t* q = my + (size_t)lane * 2 * R;
-            if ((R & 1) == 0) {
-                const unsigned* qd = reinterpret_cast<const unsigned*>(q);
-                // lane stride is S = R/2 dwords; when S shares a factor with the 32
-                // banks, start each lane's (order-free) sum at a different dword so
-                // that a 32-lane group still spreads over all banks
-                const int S = R / 2;
-                int idx = (S & 1) ? 0 : (lane * S / 32) % S;
-                for (int i = 0; i < S; ++i) {
-                    const unsigned d = qd[idx];
-                    if (++idx == S) idx = 0;
-                    si = __builtin_amdgcn_udot4(d, 0x00010001u, si, false);
-                    sq = __builtin_amdgcn_udot4(d, 0x01000100u, sq, false);
-                }
-            } else {
-                const uint16_t* qh = reinterpret_cast<const uint16_t*>(q);
-                for (int i = 0; i < R; ++i) {
-                    const unsigned s = qh[i];
-                    si += s & 0xffu;
-                    sq += s >> 8;
-                }
-            }
-            const nt_i2 o = {(int)si - 128 * R, (int)sq - 128 * R};
-            __builtin_nontemporal_store(o, dst + m0 + lane);
+        cic_release_slice();
+    }
+    const long m = npieces * 64 + lane;
+    if (blockIdx.x == 0 && wave == 0 && m < n) {
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(src) + m * R;
+        unsigned si = 0, sq = 0;
+        for (int i = 0; i < R; ++i) {
+            const unsigned x = q[i];
+            si += x & 0xffu;
+            sq += x >> 8;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const nt_i2 o = {(int)si - 128 * R, (int)sq - 128 * R};
+        dst[m] = o;
     }
 }
 
@@ -113,13 +94,20 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
                            reinterpret_cast<const nt_u4*>(d_src), reinterpret_cast<nt_i2*>(d_dst),
                            dst_len);
     } else {
-        long blocks = (dst_len + 255) / 256;
-        if (blocks > 256 * 4) blocks = 256 * 4;
-        const size_t lds = (size_t)4 * 128 * (size_t)R;
-        if (lds > 64 * 1024) return hipErrorInvalidValue;   // R <= 128
-        hipLaunchKernelGGL(cicr_kernel, dim3((unsigned)blocks), dim3(256), lds, st,
+        if (R < 1 || R > 128) return hipErrorInvalidValue;
+        // 8 KiB of LDS per wavefront (16 KiB when a piece is larger): 4 workgroups
+        // of 4 wavefronts per CU, 8 KiB in flight per wavefront
+        const int chunk = 128 * R;
+        const int slice = chunk > 8192 ? 16384 : 8192;
+        const int G = slice / chunk;
+        const long rounds = (dst_len / 64 + G - 1) / G;
+        long blocks = (rounds + 3) / 4;
+        const long cap = 256L * (slice == 8192 ? 4 : 2);
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(cicr_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * slice, st,
                            reinterpret_cast<const uint8_t*>(d_src),
-                           reinterpret_cast<nt_i2*>(d_dst), dst_len, R);
+                           reinterpret_cast<nt_i2*>(d_dst), dst_len, R, slice, G);
     }
     return hipGetLastError();
 }

@@ -54,6 +54,23 @@ def test_cic_large_block_sums(engine, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("R", [1, 2, 3, 5, 9, 10, 12, 16, 25, 63, 64, 65, 127, 128])
+def test_cic_block_sums_every_shape(engine, R):
+    """Batch entry point: lengths around the 64-output piece and around a
+    wavefront's round of pieces, every alignment class of R (odd R has a
+    half-wavefront tail copy and masked half dwords; R > 64 the larger slice)."""
+    rng = np.random.default_rng(1000 + R)
+    per_round = 64 * max(1, (8192 if R <= 64 else 16384) // (128 * R))
+    for n in (1, 63, 64, 65, per_round - 1, per_round + 64, 4 * per_round * 5 + 17, 40000):
+        src = rng.integers(0, 256, size=(n * R, 2), dtype=np.uint8)
+        d_src = engine.upload(src)
+        d_dst = engine.alloc(n * 8)
+        engine.cic_block_sums(R, d_src, n, d_dst)
+        got = engine.download(d_dst, np.int32, (n, 2))
+        want = (src.astype(np.int32) - 128).reshape(n, R, 2).sum(axis=1)
+        assert np.array_equal(got, want), (R, n)
+
+
 def test_cic_empty(built):
     rc, dst, st = built.cic_decimate(8, np.zeros((0, 2), dtype=np.uint8), state=[5, 6, 7, 8])
     assert rc == 0 and dst.shape[0] == 0 and list(st) == [5, 6, 7, 8]

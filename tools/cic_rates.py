@@ -16,8 +16,9 @@ dev = torch.device("cuda", 0)
 eng = rtlws.Engine(0)
 L = rtlws.hip_lib()
 stream = torch.cuda.current_stream().cuda_stream
-for R in (2, 3, 8, 10, 12, 16, 25, 64):
-    n_out = (1 << 24) // (R if R < 16 else R // 2)
+RS = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 5, 8, 10, 12, 16, 25, 64, 127, 128]
+for R in RS:
+    n_out = (1 << 27) // max(R, 4)
     n_out -= n_out % 64
     src = [torch.randint(0, 256, (n_out * R, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
     dst = [torch.empty((n_out, 2), dtype=torch.int32, device=dev) for _ in range(3)]

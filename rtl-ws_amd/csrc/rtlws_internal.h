@@ -47,12 +47,12 @@ struct SpectraParams {
     int cic_r;             // 1 when unused
     int n_fft;
     int out_mode;          // OUT_*
-    const float2* tw1;     // fused: [T][16] W_N^(m1*rev16(s)); direct: [N] W_N^e
-    const float2* tw2;     // fused: [16][R3] scale * W_T^(m*q2)
+    const float2* tw1;     // fused: [T][16] scale * W_N^(m1*rev16(s)); direct: [N] W_N^e
+    const float2* tw2;     // fused: [16][R3/2] last-pass (cos, sin/cos) pairs of W_T^q2
     const float* window;   // [N] or nullptr
     float db_offset;       // -10*log10(K)
     float lin_gain;        // gain / K for the payload epilogue
-    float in_scale;        // direct kernel only (fused: folded into tw2)
+    float in_scale;        // 1/128 or 1 (fused: also folded into tw1[s >= 1])
 };
 
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'

@@ -39,9 +39,9 @@ void set_err(const char* what, hipError_t e)
     } while (0)
 
 struct Tables {
-    float2* tw1 = nullptr;
-    float2* tw2_unit = nullptr;     // input scale 1      (real f32)
-    float2* tw2_128 = nullptr;      // input scale 1/128  (u8, s32, CIC)
+    float2* tw1 = nullptr;          // fused: input scale 1 (real f32); direct: W_N^e
+    float2* tw1_128 = nullptr;      // fused: input scale 1/128 (u8, s32, CIC)
+    float2* tw2 = nullptr;          // fused: last-pass (c, s/c) pairs
     float* hann = nullptr;
 };
 
@@ -63,8 +63,29 @@ int rev16h(int s) { return 4 * (s & 3) + (s >> 2); }
 
 bool is_fused_n(int n) { return n == 1024 || n == 2048 || n == 4096; }
 
+// (cos, sin/cos) of -2*pi*num/den, the form the last pass multiplies by
+// (spectrum_fused.hip, "last pass"); cos = 0 is stored as 1e-20.
+float2 cos_tan_pair(long num, long den)
+{
+    num %= den;
+    double c, sn;
+    if (4 * num == den) { c = 0.0; sn = -1.0; }
+    else if (4 * num == 3 * den) { c = 0.0; sn = 1.0; }
+    else if (2 * num == den) { c = -1.0; sn = 0.0; }
+    else if (num == 0) { c = 1.0; sn = 0.0; }
+    else {
+        const double a = -kTwoPi * (double)num / (double)den;
+        c = std::cos(a);
+        sn = std::sin(a);
+    }
+    if (c == 0.0) c = 1e-20;
+    return make_float2((float)c, (float)(sn / c));
+}
+
 // Build (once per engine and N) the per-thread twiddle tables of the fused
-// kernel: tw1[t][s] = W_N^(t * rev16(s)), tw2[q2][m] = scale * W_T^(m * q2).
+// kernel: tw1[t][s] = scale * W_N^(t * rev16(s)) (s >= 1; the kernel scales slot
+// 0 itself), tw2[q2][.] = the R3/2 pairs of alpha = W_T^q2: for sub-size
+// L = 2, 4, .. R3 and p < max(1, L/4) the pair of alpha^(R3/L) * W_L^p.
 int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
 {
     std::lock_guard<std::mutex> lk(e->mu);
@@ -74,30 +95,29 @@ int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
     Tables tb;
     HIP_TRY(hipSetDevice(e->device), -3);
     if (fused) {
-        const int T = n_fft / 16, R3 = n_fft / 256;
-        std::vector<float2> h1((size_t)T * 16), h2u((size_t)R3 * 16), h2s((size_t)R3 * 16);
+        const int T = n_fft / 16, R3 = n_fft / 256, NP = R3 / 2;
+        std::vector<float2> h1((size_t)T * 16), h1s((size_t)T * 16), h2((size_t)NP * 16);
         for (int t = 0; t < T; ++t)
             for (int s = 0; s < 16; ++s) {
                 const long ex = ((long)t * rev16h(s)) % n_fft;
                 const double a = -kTwoPi * (double)ex / (double)n_fft;
-                h1[(size_t)t * 16 + s] = make_float2((float)std::cos(a), (float)std::sin(a));
+                const float c = (float)std::cos(a), sn = (float)std::sin(a);
+                h1[(size_t)t * 16 + s] = make_float2(c, sn);
+                h1s[(size_t)t * 16 + s] = make_float2(c * 0.0078125f, sn * 0.0078125f);
             }
-        // tw2[q2][m] = scale * W_T^(m * q2): the R3 twiddles lane q2 applies to the
-        // inputs of its last-pass butterflies
-        for (int q2 = 0; q2 < 16; ++q2)
-            for (int m = 0; m < R3; ++m) {
-                const long ex = ((long)m * q2) % T;
-                const double a = -kTwoPi * (double)ex / (double)T;
-                const double c = std::cos(a), sn = std::sin(a);
-                h2u[(size_t)q2 * R3 + m] = make_float2((float)c, (float)sn);
-                h2s[(size_t)q2 * R3 + m] = make_float2((float)c * 0.0078125f, (float)sn * 0.0078125f);
-            }
+        for (int q2 = 0; q2 < 16; ++q2) {
+            int k = 0;
+            for (int L = 2; L <= R3; L *= 2)
+                for (int p = 0; p < (L >= 4 ? L / 4 : 1); ++p)
+                    // alpha^(R3/L) * W_L^p = W_(T*L)^(q2*R3 + p*T)
+                    h2[(size_t)q2 * NP + k++] = cos_tan_pair((long)q2 * R3 + (long)p * T, (long)T * L);
+        }
         HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMalloc(&tb.tw2_unit, h2u.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMalloc(&tb.tw2_128, h2s.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMalloc(&tb.tw1_128, h1s.size() * sizeof(float2)), -3);
+        HIP_TRY(hipMalloc(&tb.tw2, h2.size() * sizeof(float2)), -3);
         HIP_TRY(hipMemcpy(tb.tw1, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
-        HIP_TRY(hipMemcpy(tb.tw2_unit, h2u.data(), h2u.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
-        HIP_TRY(hipMemcpy(tb.tw2_128, h2s.data(), h2s.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        HIP_TRY(hipMemcpy(tb.tw1_128, h1s.data(), h1s.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        HIP_TRY(hipMemcpy(tb.tw2, h2.data(), h2.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
     } else {
         std::vector<float2> h1((size_t)n_fft);
         for (int k = 0; k < n_fft; ++k) {
@@ -193,8 +213,8 @@ void rtlws_engine_destroy(rtlws_engine* e)
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tables) {
         (void)hipFree(kv.second.tw1);
-        (void)hipFree(kv.second.tw2_unit);
-        (void)hipFree(kv.second.tw2_128);
+        (void)hipFree(kv.second.tw1_128);
+        (void)hipFree(kv.second.tw2);
         (void)hipFree(kv.second.hann);
     }
     (void)hipStreamDestroy(e->stream);
@@ -383,9 +403,9 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     p.cic_r = d->cic_r > 1 ? d->cic_r : 1;
     p.n_fft = d->n_fft;
     p.out_mode = d->output;
-    p.tw1 = tb.tw1;
     const bool scaled = (d->input != RTLWS_IN_RF32);
-    p.tw2 = scaled ? tb.tw2_128 : tb.tw2_unit;
+    p.tw1 = (fused && scaled) ? tb.tw1_128 : tb.tw1;
+    p.tw2 = tb.tw2;
     p.in_scale = scaled ? 0.0078125f : 1.0f;
     p.window = (d->window == RTLWS_WIN_HANN) ? tb.hann : nullptr;
     p.db_offset = (float)(-10.0 * std::log10((double)d->k_avg));

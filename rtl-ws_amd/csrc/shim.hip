@@ -38,6 +38,14 @@ void set_err(const char* what, hipError_t e)
         }                                       \
     } while (0)
 
+#define NEED_ENGINE(e, ret)                                   \
+    do {                                                      \
+        if (!(e)) {                                           \
+            g_err = std::string(__func__) + ": null engine";  \
+            return ret;                                       \
+        }                                                     \
+    } while (0)
+
 struct Tables {
     float2* tw1 = nullptr;          // fused: input scale 1 (real f32); direct: W_N^e
     float2* tw1_128 = nullptr;      // fused: input scale 1/128 (u8, s32, CIC)
@@ -82,6 +90,24 @@ float2 cos_tan_pair(long num, long den)
     return make_float2((float)c, (float)(sn / c));
 }
 
+template <typename V>
+bool upload_table(const std::vector<V>& host, V** dev)
+{
+    hipError_t err = hipMalloc(dev, host.size() * sizeof(V));
+    if (err == hipSuccess) err = hipMemcpy(*dev, host.data(), host.size() * sizeof(V), hipMemcpyHostToDevice);
+    if (err != hipSuccess) set_err("twiddle table upload", err);
+    return err == hipSuccess;
+}
+
+void free_tables(Tables& tb)
+{
+    (void)hipFree(tb.tw1);
+    (void)hipFree(tb.tw1_128);
+    (void)hipFree(tb.tw2);
+    (void)hipFree(tb.hann);
+    tb = Tables();
+}
+
 // Build (once per engine and N) the per-thread twiddle tables of the fused
 // kernel: tw1[t][s] = scale * W_N^(t * rev16(s)) (s >= 1; the kernel scales slot
 // 0 itself), tw2[q2][.] = the R3/2 pairs of alpha = W_T^q2: for sub-size
@@ -112,27 +138,26 @@ int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
                     // alpha^(R3/L) * W_L^p = W_(T*L)^(q2*R3 + p*T)
                     h2[(size_t)q2 * NP + k++] = cos_tan_pair((long)q2 * R3 + (long)p * T, (long)T * L);
         }
-        HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMalloc(&tb.tw1_128, h1s.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMalloc(&tb.tw2, h2.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMemcpy(tb.tw1, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
-        HIP_TRY(hipMemcpy(tb.tw1_128, h1s.data(), h1s.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
-        HIP_TRY(hipMemcpy(tb.tw2, h2.data(), h2.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        if (!upload_table(h1, &tb.tw1) || !upload_table(h1s, &tb.tw1_128) || !upload_table(h2, &tb.tw2)) {
+            free_tables(tb);
+            return -3;
+        }
     } else {
         std::vector<float2> h1((size_t)n_fft);
         for (int k = 0; k < n_fft; ++k) {
             const double a = -kTwoPi * (double)k / (double)n_fft;
             h1[k] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
-        HIP_TRY(hipMalloc(&tb.tw1, h1.size() * sizeof(float2)), -3);
-        HIP_TRY(hipMemcpy(tb.tw1, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice), -3);
+        if (!upload_table(h1, &tb.tw1)) return -3;
     }
     {
         std::vector<float> hw((size_t)n_fft);
         for (int n = 0; n < n_fft; ++n)
             hw[n] = (float)(0.5 - 0.5 * std::cos(kTwoPi * (double)n / (double)n_fft));
-        HIP_TRY(hipMalloc(&tb.hann, hw.size() * sizeof(float)), -3);
-        HIP_TRY(hipMemcpy(tb.hann, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice), -3);
+        if (!upload_table(hw, &tb.hann)) {
+            free_tables(tb);
+            return -3;
+        }
     }
     e->tables[key] = tb;
     *out = tb;
@@ -211,12 +236,7 @@ void rtlws_engine_destroy(rtlws_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (auto& kv : e->tables) {
-        (void)hipFree(kv.second.tw1);
-        (void)hipFree(kv.second.tw1_128);
-        (void)hipFree(kv.second.tw2);
-        (void)hipFree(kv.second.hann);
-    }
+    for (auto& kv : e->tables) free_tables(kv.second);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -242,6 +262,7 @@ const char* rtlws_last_error(void) { return g_err.c_str(); }
 
 void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes)
 {
+    NEED_ENGINE(e, nullptr);
     void* p = nullptr;
     HIP_TRY(hipSetDevice(e->device), nullptr);
     HIP_TRY(hipMalloc(&p, bytes ? bytes : 1), nullptr);
@@ -250,7 +271,7 @@ void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes)
 
 void rtlws_dev_free(rtlws_engine* e, void* dptr)
 {
-    if (!dptr) return;
+    if (!dptr || !e) return;
     (void)hipSetDevice(e->device);
     (void)hipFree(dptr);
 }
@@ -269,6 +290,7 @@ void rtlws_pinned_free(void* hptr)
 
 int rtlws_copy_h2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipSetDevice(e->device), -3);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick_stream(e, stream)), -3);
     return 0;
@@ -276,6 +298,7 @@ int rtlws_copy_h2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, vo
 
 int rtlws_copy_d2h(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipSetDevice(e->device), -3);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick_stream(e, stream)), -3);
     return 0;
@@ -283,6 +306,7 @@ int rtlws_copy_d2h(rtlws_engine* e, void* dst, const void* src, size_t bytes, vo
 
 int rtlws_memset_dev(rtlws_engine* e, void* dst, int value, size_t bytes, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipSetDevice(e->device), -3);
     HIP_TRY(hipMemsetAsync(dst, value, bytes, pick_stream(e, stream)), -3);
     return 0;
@@ -290,6 +314,7 @@ int rtlws_memset_dev(rtlws_engine* e, void* dst, int value, size_t bytes, void* 
 
 int rtlws_stream_sync(rtlws_engine* e, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipSetDevice(e->device), -3);
     HIP_TRY(hipStreamSynchronize(pick_stream(e, stream)), -3);
     return 0;
@@ -309,6 +334,7 @@ void rtlws_event_destroy(void* ev)
 
 int rtlws_event_record(void* ev, rtlws_engine* e, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), pick_stream(e, stream)), -3);
     return 0;
 }
@@ -501,6 +527,7 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_p
 
 int rtlws_copy_d2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
 {
+    NEED_ENGINE(e, -1);
     HIP_TRY(hipSetDevice(e->device), -3);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick_stream(e, stream)), -3);
     return 0;

@@ -19,7 +19,9 @@ def pytest_configure(config):
 def built():
     """Product libraries present (built in-tree by __graft_entry__.build())."""
     import rtlws
-    if not (os.path.exists(rtlws.HIP_LIB) and os.path.exists(rtlws.AMD_LIB)):
+    need = [rtlws.HIP_LIB, rtlws.AMD_LIB] + [os.path.join(rtlws.LIB_DIR, f) for f in
+                                             ("librtlws_cbb.so", "librtlws_synth.so", "rtlws_dropin_demo", "rtlws_multi_stream")]
+    if not all(os.path.exists(f) for f in need):
         rtlws.build()
     return rtlws
 

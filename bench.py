@@ -108,8 +108,9 @@ def whole_job_rate(world, steps, frames_per_step, elapsed_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500,
+                    help="untimed launches first; the clock governor needs ~300 (25 ms) to settle at the power cap")
     ap.add_argument("--workload", default="batched_1024pt_64k_frames", choices=sorted(WORKLOADS))
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -8,7 +8,7 @@ python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --workload $WL > /t
 BP=$!
 sleep 1.5
 for i in 1 2 3 4 5 6; do
-  rocm-smi --showpower --showclocks 2>/dev/null | grep -i "sclk\|mclk\|fclk\|power" | tr -s ' ' | tr '\n' ';'; echo
+  rocm-smi --showpower --showclocks 2>/dev/null | grep -i "sclk\|mclk\|fclk\|Power (W)" | sed -e 's/.*: \(.\)clk clock level: .: (\(.*\))/\1clk \2/' -e 's/.*Power (W): \(.*\)/power \1 W/' | tr '\n' ' '; echo
   sleep 0.5
 done
 wait $BP

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <chrono>
+#include <cstring>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -97,12 +99,52 @@ static void run(const char* name, kern_t k, std::vector<uint8_t*>& ins, std::vec
     fflush(stdout);
 }
 
-int main()
+// 16-byte loads: two per lane cover the frame (no transposition: the values end up
+// in the wrong lanes, which a timing-only kernel does not mind)
+__global__ __launch_bounds__(64) void k_wide(const uint8_t* __restrict__ in, float* __restrict__ out, long nframes)
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    for (long f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const u4* src = reinterpret_cast<const u4*>(in + f * 2048);
+        const u4 a = __builtin_nontemporal_load(src + t), b = __builtin_nontemporal_load(src + 64 + t);
+        float acc[16];
+        acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w; acc[4] = b.x; acc[5] = b.y; acc[6] = b.z; acc[7] = b.w;
+#pragma unroll
+        for (int r = 8; r < 16; ++r) acc[r] = acc[r - 8] * 0.5f;
+        f4* dst = reinterpret_cast<f4*>(out + f * 1024) + t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f4 o = {acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};
+            __builtin_nontemporal_store(o, dst + 64 * s);
+        }
+    }
+}
+
+// sustained mode for power sampling: policybench <u16|dma|wide> <seconds>
+static int sustained(const char* which, double seconds, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
+{
+    kern_t k = !strcmp(which, "dma") ? (kern_t)k_dma<2> : !strcmp(which, "wide") ? (kern_t)k_wide : (kern_t)k_nt_nt;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const auto t0 = std::chrono::steady_clock::now();
+    long launches = 0; double ms_total = 0.0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k, dim3(4096), dim3(64), 0, 0, ins[i % 4], outs[i % 4], nframes);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms_total += ms; launches += 200;
+    }
+    printf("%-5s %.2f us per launch over %ld launches\n", which, 1e3 * ms_total / launches, launches);
+    return 0;
+}
+
+int main(int argc, char** argv)
 {
     const long nframes = 65536;
     std::vector<uint8_t*> ins(4); std::vector<float*> outs(4);
     for (int i = 0; i < 4; ++i) { CHECK(hipMalloc(&ins[i], nframes * 2048)); CHECK(hipMalloc(&outs[i], nframes * 4096));
         CHECK(hipMemset(ins[i], 0x55 + i, nframes * 2048)); }
+    if (argc > 2) return sustained(argv[1], atof(argv[2]), ins, outs, nframes);
     for (int rep = 0; rep < 2; ++rep) {
         run("ld plain      st plain", k_plain_plain, ins, outs, nframes);
         run("ld plain      st nt", k_plain_nt, ins, outs, nframes);

@@ -121,10 +121,15 @@ __global__ __launch_bounds__(64) void k_wide(const uint8_t* __restrict__ in, flo
     }
 }
 
-// sustained mode for power sampling: policybench <u16|dma|wide> <seconds>
+// sustained mode for power sampling: policybench <u16|dma|wide|plain|ntplain|sc1|sc0sc1|sc1nt|ldsc1> <seconds>
+// (u16 = the product's nt loads + nt stores; ntplain = plain loads + nt stores; sc1.. = store policy; ldsc1 = sc1 loads)
 static int sustained(const char* which, double seconds, std::vector<uint8_t*>& ins, std::vector<float*>& outs, long nframes)
 {
-    kern_t k = !strcmp(which, "dma") ? (kern_t)k_dma<2> : !strcmp(which, "wide") ? (kern_t)k_wide : (kern_t)k_nt_nt;
+    kern_t k = !strcmp(which, "dma") ? (kern_t)k_dma<2> : !strcmp(which, "wide") ? (kern_t)k_wide
+             : !strcmp(which, "plain") ? (kern_t)k_plain_plain : !strcmp(which, "ntplain") ? (kern_t)k_plain_nt
+             : !strcmp(which, "sc1") ? (kern_t)k_nt_sc1 : !strcmp(which, "sc0sc1") ? (kern_t)k_nt_sc0sc1
+             : !strcmp(which, "sc1nt") ? (kern_t)k_nt_sc1nt : !strcmp(which, "ldsc1") ? (kern_t)k_sc1_nt
+             : (kern_t)k_nt_nt;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const auto t0 = std::chrono::steady_clock::now();
     long launches = 0; double ms_total = 0.0;

@@ -66,7 +66,9 @@ int rtlws_copy_d2h(rtlws_engine* e, void* dst_host, const void* src_dev, size_t 
 int rtlws_memset_dev(rtlws_engine* e, void* dst_dev, int value, size_t bytes, void* stream);
 int rtlws_stream_sync(rtlws_engine* e, void* stream);
 
-/* hipEvent timing on a stream, for bench.py's roofline leg. */
+/* hipEvent timing on a stream, for bench.py's roofline leg.  A handle binds to
+ * the device of the engine it is first recorded on (any thread, whatever its
+ * current device is). */
 void* rtlws_event_create(void);
 void rtlws_event_destroy(void* ev);
 int rtlws_event_record(void* ev, rtlws_engine* e, void* stream);
@@ -126,6 +128,27 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* desc, const v
 int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int count, int gain_db,
                             void* d_out_u8, void* stream);
 
+/* ---- the same, in the reference's own precision (f64) -----------------------
+ *
+ * The reference converts to double, runs an f64 DFT and accumulates into the
+ * caller's double buffer (src/spectrum.c:21-34,54-58); cbb_main.c does the
+ * dB / truncate / clamp in double (src/cbb_main.c:112,121-130).  The
+ * reference-API paths -- spectrum_add_* (spectrum.h) and cbb_main.h -- move
+ * one to six frames per call, so they go through this entry point: same
+ * descriptor, same semantics and frame layout as rtlws_spectra_batch, f64
+ * arithmetic, any 2 <= n_fft <= 8192 (radix-2 in LDS for powers of two, the
+ * direct sum otherwise), one workgroup per output row.
+ *   RTLWS_OUT_POWER_SUM / RTLWS_OUT_MEAN_DB : d_out rows of n_fft doubles
+ *   RTLWS_OUT_PAYLOAD_U8                    : d_out rows of n_fft bytes,
+ *       clamp((int)(10*log10(fabs(g*sum/K))), 0, 255) evaluated in double
+ * d_in / d_out 8-byte aligned.  0 / -1 / -3. */
+int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
+                            long nframes, void* d_out, void* stream);
+
+/* src/cbb_main.c:112,121-130 on f64 sums that live on the device, in double. */
+int rtlws_payload_from_sums_f64(rtlws_engine* e, const double* d_sums, int n, int count, int gain_db,
+                                void* d_out_u8, void* stream);
+
 /* Which kernel a descriptor selects: 1 fused, 2 direct DFT, 0 unsupported. */
 int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* desc);
 
@@ -146,7 +169,7 @@ int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, 
  * with atan2_approx of src/common_sp.h:40-76):
  *   phase_i = atan2_approx((float)im_i, (float)re_i)
  *   out_i   = clamp(phase_i - phase_{i-1}, -1, 1),   phase_{-1} = *d_prev_in
- * and *d_prev_out = phase_{len-1}.  d_iq: len cmplx_s32; all pointers device;
+ * and *d_prev_out = phase_{len-1} (len = 0: *d_prev_out = *d_prev_in).  d_iq: len cmplx_s32; all pointers device;
  * d_prev_in and d_prev_out must differ.  Bit-identical to an IEEE evaluation
  * of the reference's expressions.  0 / -1 / -3. */
 int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float* d_prev_in,

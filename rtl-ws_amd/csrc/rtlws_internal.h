@@ -55,22 +55,51 @@ struct SpectraParams {
     float in_scale;        // 1/128 or 1 (fused: also folded into tw1[s >= 1])
 };
 
+// The f64 ("exact") kernel of spectrum_f64.hip: reference-precision arithmetic
+// for the reference-API paths (spectrum.h, cbb_main.h).
+struct SpectraParamsF64 {
+    const void* in;        // device: frames
+    void* out;             // device: rows (f64, or u8 for OUT_PAYLOAD)
+    long ngroups;
+    int k_avg;
+    int cic_r;             // 1 when unused
+    int n_fft;             // 2 .. 8192
+    int log2n;             // log2(n_fft) when it is a power of two, else 0 (direct sum)
+    int out_mode;          // OUT_*
+    int count;             // divisor of the dB / payload epilogues (= k_avg)
+    const double2* tw;     // [N] W_N^k, built in long double, rounded once
+    const double* window;  // [N] or nullptr
+    double lin_gain;       // 10^(gain_db/10), C integer division (src/cbb_main.c:112)
+    double in_scale;       // 1/128 or 1
+};
+
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
-// second argument), by instantiation.  N = 1024 fits 4 (120 VGPRs).  The larger
-// sizes carry R3 = 8 or 16 last-pass twiddles and a bigger last pass and spill at
-// 128 VGPRs, so they are built for 3 (<= 168 VGPRs) -- except the CIC-fused
-// rectangular 2048-point variants, which have no prefetch registers, fit 128 and
-// are latency-bound on their loads, so they want every wave they can get.
+// second argument), by instantiation, chosen so that NO instantiation spills
+// (tests/test_abi_cpu.py reads the code-object metadata and fails on any
+// vgpr_spill_count > 0).  4 waves/SIMD = 128 VGPRs, 3 = 168.
+//   N = 1024: the rectangular K = 1 kernels (118-121 VGPRs) and every
+//     rectangular kind without prefetch registers or accumulators fit 4; a
+//     window (16 more registers) or K > 1 on the two prefetching kinds needs 3.
+//   N = 2048: the CIC-fused rectangular kinds fit 4 and are latency-bound on
+//     their loads, so they want every wave they can get; the rest carry R3 = 8
+//     last-pass twiddles and are built for 3.
+//   N = 4096: 3 (R3 = 16 twiddles and a bigger last pass).
 // RTLWS_WAVES_BIG overrides the "3" for experiments.
 #ifndef RTLWS_WAVES_BIG
 #define RTLWS_WAVES_BIG 3
 #endif
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
-    return n_fft == 1024 ? 4
-           : (in_kind >= IN_CU8_CIC8 && !win && n_fft == 2048) ? 4
+    const bool acc_and_prefetch = !kone && (in_kind == IN_CU8 || in_kind == IN_CU8_CIC8);
+    return (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
+           : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
            : RTLWS_WAVES_BIG;
 }
+
+// One-frame-ahead prefetch of the raw cmplx_u8 bytes (16 VGPRs).  Worth <= 2 % at
+// 12-16 resident wavefronts per CU; the windowed 4096-point kernels have no
+// room for it at 168 VGPRs, so they load in the loop instead of spilling.
+constexpr bool fused_prefetch_u8(int n_fft, bool win) { return !(n_fft == 4096 && win); }
 
 // LDS the fused kernel needs, in float2 units: 16 (padded) rows + one spare slot
 // (layouts: spectrum_fused.hip, "LDS layouts").
@@ -89,6 +118,8 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
 hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
                            float* d_out, hipStream_t);
 hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t);
+hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t);
+hipError_t launch_payload_f64(const double* d_sums, int n, double gain, int count, uint8_t* d_out, hipStream_t);
 
 }  // namespace rtlws
 #endif

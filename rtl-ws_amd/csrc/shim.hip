@@ -51,6 +51,8 @@ struct Tables {
     float2* tw1_128 = nullptr;      // fused: input scale 1/128 (u8, s32, CIC)
     float2* tw2 = nullptr;          // fused: last-pass (c, s/c) pairs
     float* hann = nullptr;
+    double2* tw64 = nullptr;        // f64 kernel: W_N^k, k < N
+    double* hann64 = nullptr;
 };
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;
@@ -105,6 +107,8 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.tw1_128);
     (void)hipFree(tb.tw2);
     (void)hipFree(tb.hann);
+    (void)hipFree(tb.tw64);
+    (void)hipFree(tb.hann64);
     tb = Tables();
 }
 
@@ -160,6 +164,44 @@ int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
         }
     }
     e->tables[key] = tb;
+    *out = tb;
+    return 0;
+}
+
+// Tables of the f64 kernel (spectrum_f64.hip), once per engine and N: W_N^k for
+// k < N evaluated in long double and rounded once (axis values exact); periodic
+// Hann in double.
+constexpr int kF64Key = 1 << 24;
+
+int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    auto it = e->tables.find(kF64Key + n_fft);
+    if (it != e->tables.end()) { *out = it->second; return 0; }
+    Tables tb;
+    HIP_TRY(hipSetDevice(e->device), -3);
+    std::vector<double2> hw((size_t)n_fft);
+    std::vector<double> hh((size_t)n_fft);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < n_fft; ++k) {
+        long double c, sn;                         // exp(-2*pi*i*k/N)
+        if (k == 0) { c = 1.0L; sn = 0.0L; }
+        else if (4L * k == n_fft) { c = 0.0L; sn = -1.0L; }
+        else if (2L * k == n_fft) { c = -1.0L; sn = 0.0L; }
+        else if (4L * k == 3L * n_fft) { c = 0.0L; sn = 1.0L; }
+        else {
+            const long double a = -two_pi * (long double)k / (long double)n_fft;
+            c = cosl(a);
+            sn = sinl(a);
+        }
+        hw[k] = make_double2((double)c, (double)sn);
+        hh[k] = (double)(0.5L - 0.5L * cosl(two_pi * (long double)k / (long double)n_fft));
+    }
+    if (!upload_table(hw, &tb.tw64) || !upload_table(hh, &tb.hann64)) {
+        free_tables(tb);
+        return -3;
+    }
+    e->tables[kF64Key + n_fft] = tb;
     *out = tb;
     return 0;
 }
@@ -320,37 +362,70 @@ int rtlws_stream_sync(rtlws_engine* e, void* stream)
     return 0;
 }
 
+// An event handle is {hipEvent_t, device}: the HIP event is created on the
+// device of the engine it is first recorded on (a HIP event belongs to the
+// device that was current when it was created, which need not be the engine's
+// on a multi-GPU host), and re-created if it is later recorded on another one.
+struct rtlws_event {
+    hipEvent_t ev = nullptr;
+    int device = -1;
+};
+
 void* rtlws_event_create(void)
 {
-    hipEvent_t ev = nullptr;
-    HIP_TRY(hipEventCreate(&ev), nullptr);
-    return ev;
+    return new rtlws_event;
 }
 
 void rtlws_event_destroy(void* ev)
 {
-    if (ev) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev));
+    rtlws_event* x = reinterpret_cast<rtlws_event*>(ev);
+    if (!x) return;
+    if (x->ev) {
+        (void)hipSetDevice(x->device);
+        (void)hipEventDestroy(x->ev);
+    }
+    delete x;
 }
 
 int rtlws_event_record(void* ev, rtlws_engine* e, void* stream)
 {
     NEED_ENGINE(e, -1);
-    HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), pick_stream(e, stream)), -3);
+    rtlws_event* x = reinterpret_cast<rtlws_event*>(ev);
+    if (!x) { g_err = "rtlws_event_record: null event"; return -1; }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    if (x->ev && x->device != e->device) {
+        (void)hipEventDestroy(x->ev);
+        x->ev = nullptr;
+    }
+    if (!x->ev) {
+        HIP_TRY(hipEventCreate(&x->ev), -3);
+        x->device = e->device;
+    }
+    HIP_TRY(hipEventRecord(x->ev, pick_stream(e, stream)), -3);
     return 0;
 }
 
 int rtlws_event_sync(void* ev)
 {
-    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)), -3);
+    rtlws_event* x = reinterpret_cast<rtlws_event*>(ev);
+    if (!x || !x->ev) { g_err = "rtlws_event_sync: event was never recorded"; return -1; }
+    HIP_TRY(hipSetDevice(x->device), -3);
+    HIP_TRY(hipEventSynchronize(x->ev), -3);
     return 0;
 }
 
 float rtlws_event_elapsed_ms(void* start, void* stop)
 {
+    rtlws_event* a = reinterpret_cast<rtlws_event*>(start);
+    rtlws_event* b = reinterpret_cast<rtlws_event*>(stop);
     float ms = -1.0f;
-    HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)), -1.0f);
-    HIP_TRY(hipEventElapsedTime(&ms, reinterpret_cast<hipEvent_t>(start),
-                                reinterpret_cast<hipEvent_t>(stop)), -1.0f);
+    if (!a || !b || !a->ev || !b->ev || a->device != b->device) {
+        g_err = "rtlws_event_elapsed_ms: events must both be recorded, on the same device";
+        return -1.0f;
+    }
+    HIP_TRY(hipSetDevice(a->device), -1.0f);
+    HIP_TRY(hipEventSynchronize(b->ev), -1.0f);
+    HIP_TRY(hipEventElapsedTime(&ms, a->ev, b->ev), -1.0f);
     return ms;
 }
 
@@ -482,6 +557,68 @@ int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int cou
     return 0;
 }
 
+int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const void* d_in,
+                            long nframes, void* d_out, void* stream)
+{
+    g_err.clear();
+    if (!e || !desc_ok(d) || d->n_fft > 8192 || !d_in || !d_out || nframes < 0 || nframes % d->k_avg) {
+        g_err = "rtlws_spectra_batch_f64: bad descriptor (2 <= n_fft <= 8192), pointer or frame count";
+        return -1;
+    }
+    if (nframes == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 7u) || (reinterpret_cast<uintptr_t>(d_out) & 7u)) {
+        g_err = "rtlws_spectra_batch_f64: d_in and d_out must be 8-byte aligned";
+        return -1;
+    }
+    Tables tb;
+    if (get_tables_f64(e, d->n_fft, &tb) != 0) return -3;
+
+    rtlws::SpectraParamsF64 p;
+    std::memset(&p, 0, sizeof p);
+    p.in = d_in;
+    p.out = d_out;
+    p.ngroups = nframes / d->k_avg;
+    p.k_avg = d->k_avg;
+    p.cic_r = d->cic_r > 1 ? d->cic_r : 1;
+    p.n_fft = d->n_fft;
+    p.log2n = 0;
+    if ((d->n_fft & (d->n_fft - 1)) == 0)
+        for (int n = d->n_fft; n > 1; n >>= 1) ++p.log2n;
+    p.out_mode = d->output;
+    p.count = d->k_avg;
+    p.tw = tb.tw64;
+    p.window = (d->window == RTLWS_WIN_HANN) ? tb.hann64 : nullptr;
+    // reference src/cbb_main.c:112: pow(10, gain_db/10) with C integer division
+    p.lin_gain = std::pow(10.0, (double)(d->gain_db / 10));
+    p.in_scale = (d->input != RTLWS_IN_RF32) ? 0.0078125 : 1.0;
+
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_spectra_f64(p, d->input, pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("f64 spectra kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
+int rtlws_payload_from_sums_f64(rtlws_engine* e, const double* d_sums, int n, int count, int gain_db,
+                                void* d_out, void* stream)
+{
+    g_err.clear();
+    if (!e || n < 0 || count <= 0 || (n > 0 && (!d_sums || !d_out))) {
+        g_err = "rtlws_payload_from_sums_f64: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_payload_f64(d_sums, n, std::pow(10.0, (double)(gain_db / 10)), count,
+                                               reinterpret_cast<uint8_t*>(d_out), pick_stream(e, stream));
+    if (err != hipSuccess) {
+        set_err("f64 payload kernel launch", err);
+        return -3;
+    }
+    return 0;
+}
+
 int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len, void* d_dst,
                          void* stream)
 {
@@ -517,6 +654,11 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_p
         return -1;
     }
     HIP_TRY(hipSetDevice(e->device), -3);
+    if (len == 0) {   // nothing to demodulate: the carried phase passes through
+        HIP_TRY(hipMemcpyAsync(d_prev_out, d_prev_in, sizeof(float), hipMemcpyDeviceToDevice,
+                               pick_stream(e, stream)), -3);
+        return 0;
+    }
     hipError_t err = rtlws::launch_fm_demod(d_iq, len, d_prev_in, d_prev_out, d_out, pick_stream(e, stream));
     if (err != hipSuccess) {
         set_err("fm_demod kernel launch", err);

@@ -2,10 +2,18 @@
  *
  * Replaces reference src/cbb_main.c:1-153.  Per sensor buffer (worker thread):
  * count samples, feed the decimator, and -- at most every 250 ms -- turn the
- * first min(len/1024, 6) frames into ONE launch of the fused kernel (K =
- * blocks, f32 power sums that stay on the device).  On the server thread,
- * cbb_get_spectrum_payload runs the dB/clamp kernel on the published sums and
- * brings back the 1024 bytes main.c sends to the browser.
+ * first min(len/1024, 6) frames into ONE launch of the f64 kernel (K = blocks;
+ * double power sums, as reference src/cbb_main.c:27,50-59 keeps them, that
+ * stay on the device).  On the server thread, cbb_get_spectrum_payload runs
+ * the dB/clamp kernel -- in double, src/cbb_main.c:125 -- on the published
+ * sums and brings back the 1024 bytes main.c sends to the browser.
+ *
+ * The sensor thread never waits for the device: it copies
+ * the frames into one of two pinned slots, enqueues the H2D copy and the kernel
+ * on the engine's stream and returns; the only wait is on a slot whose copy
+ * from two estimates (>= 500 ms) ago has not finished, which does not happen.
+ * The server thread's payload kernel is ordered behind it on the same stream
+ * and is the one that synchronises.
  *
  * The sensor (rtl_sensor.h) and the signal source (signal_source.h) are NOT
  * part of this file: they are the reference's own units, or the synthetic
@@ -34,10 +42,14 @@ static rtlws_engine* g_eng = NULL;
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;   /* device work + published state */
 static void* g_d_iq = NULL;             /* FFT_AVERAGE frames of cmplx_u8 */
-static float* g_d_work = NULL;          /* sums being produced            */
-static float* g_d_pub = NULL;           /* sums the server thread reads   */
+static double* g_d_work = NULL;         /* sums being produced            */
+static double* g_d_pub = NULL;          /* sums the server thread reads   */
 static void* g_d_payload = NULL;
-static cmplx_u8* g_h_iq = NULL;         /* pinned */
+#define IQ_SLOTS 2
+static cmplx_u8* g_h_iq[IQ_SLOTS];      /* pinned staging slots, used in turn      */
+static void* g_iq_done[IQ_SLOTS];       /* event: that slot's H2D copy has finished */
+static int g_iq_used[IQ_SLOTS];
+static int g_iq_next = 0;
 static unsigned char* g_h_payload = NULL;
 static int g_pub_count = 0;             /* frames behind g_d_pub */
 static uint64_t g_last_est_ms = 0;
@@ -85,10 +97,14 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
         d.input = RTLWS_IN_CU8;
         d.window = RTLWS_WIN_RECT;
         d.output = RTLWS_OUT_POWER_SUM;
-        memcpy(g_h_iq, signal, bytes);
-        if (rtlws_copy_h2d(g_eng, g_d_iq, g_h_iq, bytes, NULL) ||
-            rtlws_spectra_batch(g_eng, &d, g_d_iq, blocks, g_d_work, NULL) ||
-            rtlws_stream_sync(g_eng, NULL)) {
+        const int slot = g_iq_next;
+        g_iq_next = (g_iq_next + 1) % IQ_SLOTS;
+        if (g_iq_used[slot]) rtlws_event_sync(g_iq_done[slot]);   /* copy of 2 estimates ago */
+        memcpy(g_h_iq[slot], signal, bytes);
+        g_iq_used[slot] = 1;
+        if (rtlws_copy_h2d(g_eng, g_d_iq, g_h_iq[slot], bytes, NULL) ||
+            rtlws_event_record(g_iq_done[slot], g_eng, NULL) ||
+            rtlws_spectra_batch_f64(g_eng, &d, g_d_iq, blocks, g_d_work, NULL)) {
             fprintf(stderr, "rtlws: estimate_spectrum: device failure: %s\n", rtlws_last_error());
             pthread_mutex_unlock(&g_mu);
             return;                                               /* :54-58 */
@@ -97,7 +113,7 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
     g_last_est_ms = now_ms();                                     /* :61 */
     g_new_spectrum = 1;                                           /* :62 */
     {   /* publish: swap instead of the reference's 8 KiB memcpy (:64-69) */
-        float* t = g_d_pub;
+        double* t = g_d_pub;
         g_d_pub = g_d_work;
         g_d_work = t;
         g_pub_count = blocks;
@@ -125,12 +141,21 @@ void cbb_init(int decimated_bw_target_hz)
         g_max_blocks = (all && atoi(all) > 0) ? MAX_BLOCKS_ALL : FFT_AVERAGE;
     }
     g_d_iq = rtlws_dev_alloc(g_eng, (size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
-    g_d_work = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
-    g_d_pub = (float*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(float));
+    g_d_work = (double*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(double));
+    g_d_pub = (double*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(double));
     g_d_payload = rtlws_dev_alloc(g_eng, FFT_POINTS);
-    g_h_iq = (cmplx_u8*)rtlws_pinned_alloc((size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
+    {
+        int k;
+        for (k = 0; k < IQ_SLOTS; ++k) {
+            g_h_iq[k] = (cmplx_u8*)rtlws_pinned_alloc((size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
+            g_iq_done[k] = rtlws_event_create();
+            g_iq_used[k] = 0;
+        }
+        g_iq_next = 0;
+    }
     g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
-    if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_h_iq || !g_h_payload) {
+    if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_h_iq[0] || !g_h_iq[1] ||
+        !g_iq_done[0] || !g_iq_done[1] || !g_h_payload) {
         fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
         abort();
     }
@@ -156,7 +181,7 @@ int cbb_get_spectrum_payload(char* buf, int buf_len, int spectrum_gain_db)
     int len = 0;
     pthread_mutex_lock(&g_mu);
     if (g_pub_count > 0) {                                        /* :121 */
-        if (rtlws_payload_from_sums(g_eng, g_d_pub, FFT_POINTS, g_pub_count, spectrum_gain_db,
+        if (rtlws_payload_from_sums_f64(g_eng, g_d_pub, FFT_POINTS, g_pub_count, spectrum_gain_db,
                                     g_d_payload, NULL) ||
             rtlws_copy_d2h(g_eng, g_h_payload, g_d_payload, FFT_POINTS, NULL) ||
             rtlws_stream_sync(g_eng, NULL)) {
@@ -183,7 +208,16 @@ void cbb_close(void)
         rtlws_dev_free(g_eng, g_d_work);
         rtlws_dev_free(g_eng, g_d_pub);
         rtlws_dev_free(g_eng, g_d_payload);
-        rtlws_pinned_free(g_h_iq);
+        {
+            int k;
+            rtlws_stream_sync(g_eng, NULL);
+            for (k = 0; k < IQ_SLOTS; ++k) {
+                rtlws_pinned_free(g_h_iq[k]);
+                rtlws_event_destroy(g_iq_done[k]);
+                g_h_iq[k] = NULL;
+                g_iq_done[k] = NULL;
+            }
+        }
         rtlws_pinned_free(g_h_payload);
         rtlws_engine_destroy(g_eng);                              /* replaces spectrum_free, :145 */
         g_eng = NULL;

@@ -1,11 +1,15 @@
 /* spectrum_gpu.c -- spectrum.h (drop-in boundary #1) over the HIP shim.
  *
  * Replaces reference src/spectrum.c:37-107.  The device does conversion,
- * FFT, |X|^2 and the fft-shift for one frame (rtlws_spectra_batch with one
- * frame, K = 1); this file moves the frame across PCIe and performs the
- * read-modify-write into the caller's host f64 buffer, including the
- * order-dependent DC-slot rule of reference src/spectrum.c:25-33, because
- * that buffer belongs to the caller and lives in host memory.
+ * DFT, |X|^2 and the fft-shift for one frame IN DOUBLE, as the reference does
+ * (rtlws_spectra_batch_f64 with one frame, K = 1: src/spectrum.c:54-58 converts
+ * to double, :21 is an f64 FFTW plan, :28 accumulates doubles); this file moves
+ * the frame across PCIe and performs the read-modify-write into the caller's
+ * host f64 buffer, including the order-dependent DC-slot rule of reference
+ * src/spectrum.c:25-33, because that buffer belongs to the caller and lives in
+ * host memory.  One frame per call is launch- and PCIe-bound whatever the
+ * arithmetic costs, so nothing is gained by computing it in f32; the f32 fused
+ * kernel is the batch API's (rtlws_hip.h).
  */
 #include "spectrum.h"
 
@@ -20,9 +24,9 @@ struct spectrum {
     int N;
     rtlws_engine* eng;
     void* d_in;       /* N * 8 bytes: large enough for cmplx_s32 */
-    float* d_out;     /* N floats */
+    double* d_out;    /* N doubles */
     void* h_in;       /* pinned */
-    float* h_out;     /* pinned */
+    double* h_out;    /* pinned */
 };
 
 struct spectrum* spectrum_alloc(int N)
@@ -32,7 +36,7 @@ struct spectrum* spectrum_alloc(int N)
     memset(&probe, 0, sizeof probe);
     probe.n_fft = N;
     probe.k_avg = 1;
-    if (rtlws_spectra_kernel_kind(&probe) == 0) {
+    if (rtlws_spectra_kernel_kind(&probe) == 0 || N > 8192) {
         fprintf(stderr, "rtlws: spectrum_alloc(%d): size not supported by the device engine\n", N);
         return NULL;
     }
@@ -46,9 +50,9 @@ struct spectrum* spectrum_alloc(int N)
         return NULL;
     }
     s->d_in = rtlws_dev_alloc(s->eng, (size_t)N * sizeof(cmplx_s32));
-    s->d_out = (float*)rtlws_dev_alloc(s->eng, (size_t)N * sizeof(float));
+    s->d_out = (double*)rtlws_dev_alloc(s->eng, (size_t)N * sizeof(double));
     s->h_in = rtlws_pinned_alloc((size_t)N * sizeof(cmplx_s32));
-    s->h_out = (float*)rtlws_pinned_alloc((size_t)N * sizeof(float));
+    s->h_out = (double*)rtlws_pinned_alloc((size_t)N * sizeof(double));
     if (!s->d_in || !s->d_out || !s->h_in || !s->h_out) {
         fprintf(stderr, "rtlws: spectrum_alloc: %s\n", rtlws_last_error());
         spectrum_free(s);
@@ -77,8 +81,8 @@ static int add_frame(struct spectrum* s, const void* src, size_t sample_bytes, i
 
     memcpy(s->h_in, src, (size_t)N * sample_bytes);
     if (rtlws_copy_h2d(s->eng, s->d_in, s->h_in, (size_t)N * sample_bytes, NULL) ||
-        rtlws_spectra_batch(s->eng, &d, s->d_in, 1, s->d_out, NULL) ||
-        rtlws_copy_d2h(s->eng, s->h_out, s->d_out, (size_t)N * sizeof(float), NULL) ||
+        rtlws_spectra_batch_f64(s->eng, &d, s->d_in, 1, s->d_out, NULL) ||
+        rtlws_copy_d2h(s->eng, s->h_out, s->d_out, (size_t)N * sizeof(double), NULL) ||
         rtlws_stream_sync(s->eng, NULL)) {
         fprintf(stderr, "rtlws: spectrum_add: device failure: %s\n", rtlws_last_error());
         return -3;
@@ -89,7 +93,7 @@ static int add_frame(struct spectrum* s, const void* src, size_t sample_bytes, i
      * value (reference src/spectrum.c:25-33). */
     for (i = 0; i < len; i++) {
         if ((offset + i) % len > 0)
-            power_spectrum[i] += (double)s->h_out[i];
+            power_spectrum[i] += s->h_out[i];
         else
             power_spectrum[i] += power_spectrum[i - 1];
     }

@@ -64,7 +64,7 @@ HIP_SYMBOLS = [
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
     "rtlws_event_elapsed_ms", "rtlws_event_sync", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
     "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
-    "rtlws_fm_demod", "rtlws_copy_d2d",
+    "rtlws_fm_demod", "rtlws_copy_d2d", "rtlws_spectra_batch_f64", "rtlws_payload_from_sums_f64",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
@@ -136,6 +136,8 @@ def hip_lib():
         L.rtlws_event_sync.argtypes = [vp]
         L.rtlws_event_elapsed_ms.restype = C.c_float
         L.rtlws_spectra_batch.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
+        L.rtlws_spectra_batch_f64.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
+        L.rtlws_payload_from_sums_f64.argtypes = [vp, vp, i, i, i, vp, vp]
         L.rtlws_spectra_kernel_kind.argtypes = [C.POINTER(SpectraDesc)]
         L.rtlws_cic_block_sums.argtypes = [vp, i, vp, l, vp, vp]
         L.rtlws_halfband.argtypes = [vp, vp, vp, l, vp]
@@ -271,6 +273,13 @@ class Engine:
             self._chk(rc, "rtlws_spectra_batch")
         return rc
 
+    def spectra_batch_f64(self, desc, d_in, nframes, d_out, stream=None, check=True):
+        rc = hip_lib().rtlws_spectra_batch_f64(self.h, C.byref(desc), self._ptr(d_in), int(nframes),
+                                               self._ptr(d_out), stream)
+        if check:
+            self._chk(rc, "rtlws_spectra_batch_f64")
+        return rc
+
     def cic_block_sums(self, R, d_src, dst_len, d_dst, stream=None, check=True):
         rc = hip_lib().rtlws_cic_block_sums(self.h, int(R), self._ptr(d_src), int(dst_len),
                                             self._ptr(d_dst), stream)
@@ -290,17 +299,18 @@ class Engine:
 
     # -- convenience: host arrays in, host arrays out ------------------------
     def spectra(self, data, n_fft, k_avg=1, input="cu8", window="rect", output="power_sum",
-                cic_r=0, gain_db=0):
+                cic_r=0, gain_db=0, f64=False):
+        """f64=True: rtlws_spectra_batch_f64 (the reference-precision kernel, f64 rows)."""
         desc = make_desc(n_fft, k_avg, input, window, output, cic_r, gain_db)
         data = np.ascontiguousarray(data)
         per_sample = {"cu8": 2, "cs32": 8, "rf32": 4}[input] * max(int(cic_r), 1)
         nframes = data.nbytes // (per_sample * n_fft)
         assert nframes * per_sample * n_fft == data.nbytes
         rows = nframes // k_avg
-        out_dtype = np.uint8 if output == "payload_u8" else np.float32
+        out_dtype = np.uint8 if output == "payload_u8" else (np.float64 if f64 else np.float32)
         d_in = self.upload(data)
         d_out = self.alloc(rows * n_fft * np.dtype(out_dtype).itemsize)
-        self.spectra_batch(desc, d_in, nframes, d_out)
+        (self.spectra_batch_f64 if f64 else self.spectra_batch)(desc, d_in, nframes, d_out)
         res = self.download(d_out, out_dtype, (rows, n_fft))
         d_in.free()
         d_out.free()

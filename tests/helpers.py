@@ -11,6 +11,15 @@ import numpy as np
 EPS_K1 = 1e-5
 EPS_STRICT = 1e-9
 TOL = 1e-4
+# The reference-API paths (spectrum.h, cbb_main.h) and rtlws_spectra_batch_f64
+# compute in double like the reference: they are held to the strict metric
+# (eps = 1e-9) at every K, four orders inside north_star's 1e-4.
+TOL_F64 = 1e-10
+# Guard rails for the f32 batch kernel under the STRICT metric at K = 1 (what
+# DESIGN.md "Error budget" reports: max 1.3e-3..3.5e-3, p99.9 3e-5..1.5e-4): a
+# regression in the f32 arithmetic must not hide behind the relaxed floor.
+STRICT_K1_P999 = 1e-4
+STRICT_K1_MAX = 5e-3
 
 
 def eps_for(K):
@@ -23,3 +32,9 @@ def rel_err(got, ref, eps=EPS_STRICT):
     floor = eps * np.abs(ref).max(axis=-1, keepdims=True)
     floor = np.where(floor > 0, floor, 1.0)       # all-zero rows: absolute error
     return np.abs(got - ref) / np.maximum(np.abs(ref), floor)
+
+
+def strict_stats(got, ref):
+    """(max, 99.9th percentile) of the strict-floor (eps = 1e-9) relative error."""
+    e = rel_err(got, ref, EPS_STRICT)
+    return float(e.max()), float(np.percentile(e, 99.9))

@@ -95,3 +95,30 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"pyoracle|rtlws_oracle|orc_[a-z]", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_no_kernel_spills_registers(built):
+    """Code-object metadata of librtlws_hip.so (NT_AMDGPU_METADATA, read with
+    llvm-readelf; no GPU needed): no kernel of the product may spill VGPRs or
+    SGPRs or use scratch.  A spilling instantiation writes its registers to HBM
+    on every frame (round 1: 1.33x write amplification on the 4096-point Hann
+    kernel), so the occupancy each instantiation is built for
+    (rtlws_internal.h, fused_waves_per_simd) must leave it enough registers."""
+    from rtlws import codeobj
+    ks = codeobj.kernels(built.HIP_LIB)
+    fused = [k for k in ks if "spectra_fused" in k["name"]]
+    assert len(fused) >= 200                       # every (N, input, window, output, K==1) instantiation
+    names = " ".join(k.get("demangled", "") for k in ks)
+    for want in ("spectra_f64", "spectra_direct", "cic8_kernel", "cicr_kernel", "halfband_kernel",
+                 "fm_demod_kernel", "payload_kernel", "payload_f64_kernel"):
+        assert want in names, want
+    # (the f64 kernel parks scalar lane masks of its 32 unrolled slots in a VGPR --
+    # an SGPR "spill" that never leaves the register file; it is not a throughput kernel)
+    bad = [(k.get("demangled", k["name"]), k["vgpr_spill_count"], k.get("sgpr_spill_count", 0),
+            k["private_segment_fixed_size"]) for k in ks
+           if k["vgpr_spill_count"] or k["private_segment_fixed_size"]
+           or (k.get("sgpr_spill_count", 0) and "spectra_f64" not in k["name"])]
+    assert not bad, bad
+    # the headline kernel keeps its 4 waves/SIMD (<= 128 VGPRs)
+    head = [k for k in fused if "spectra_fused<1024, 0, false, 0, true>" in k.get("demangled", "")]
+    assert len(head) == 1 and head[0]["vgpr_count"] <= 128

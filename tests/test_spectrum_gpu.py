@@ -6,7 +6,8 @@ Tolerance (north_star): <= 1e-4 relative per bin, metric
 import numpy as np
 import pytest
 
-from helpers import rel_err, eps_for, EPS_K1, TOL
+from helpers import (rel_err, eps_for, strict_stats, EPS_K1, EPS_STRICT, TOL, TOL_F64,
+                     STRICT_K1_P999, STRICT_K1_MAX)
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +23,24 @@ def test_batch_u8_vs_oracle(engine, oracle, N, K):
         ref = oracle.batch_spectra_u8(iq, N, K=K, nthreads=8)
         err = rel_err(got, ref, eps_for(K))
         assert err.max() <= TOL, (N, K, err.max())
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+def test_strict_metric_guard_k1(engine, oracle, N):
+    """The f32 kernel under the strict floor (eps = 1e-9) at K = 1: not the pass
+    criterion of the f32 batch API (helpers.py says why), but bounded so that it
+    cannot regress unseen; tone + noise is BASELINE's input, the pure tone the worst case."""
+    from rtlws import synth
+    # BASELINE's distribution (tone 0.6 + noise 0.05): the bounds VERDICT r1 item 6 names
+    iq = synth.tone_noise_iq(2048, N, seed=N + 19)
+    mx, p999 = strict_stats(engine.spectra(iq, N), oracle.batch_spectra_u8(iq, N, nthreads=8))
+    print("strict K=1 N=%d tone+noise: max %.3g p99.9 %.3g" % (N, mx, p999))
+    assert mx <= STRICT_K1_MAX and p999 <= STRICT_K1_P999, (N, mx, p999)
+    # widest dynamic range: full-scale tone, quantisation noise only
+    iq = synth.pure_tone_iq(512, N, seed=N + 18)
+    mx, p999 = strict_stats(engine.spectra(iq, N), oracle.batch_spectra_u8(iq, N, nthreads=8))
+    print("strict K=1 N=%d pure tone: max %.3g p99.9 %.3g" % (N, mx, p999))
+    assert mx <= 4 * STRICT_K1_MAX and p999 <= 5 * STRICT_K1_P999, (N, mx, p999)
 
 
 def test_many_rows_persistent_loop(engine, oracle):
@@ -174,13 +193,13 @@ def test_dropin_accumulates_like_reference(built, oracle):
     for k in range(6):
         assert s.add_cmplx_u8(iq[k], ps) == 0
         assert oracle.spectrum_add_cmplx_u8(1024, iq[k], ps_ref) == 0
-        assert rel_err(ps, ps_ref, eps_for(k + 1)).max() <= TOL
+        assert rel_err(ps, ps_ref, EPS_STRICT).max() <= TOL_F64     # f64 like the reference, every K
     # non-zero starting buffer: results are ADDED (read-modify-write)
     ps2 = np.full(1024, 3.5)
     ref2 = np.full(1024, 3.5)
     s.add_cmplx_u8(iq[0], ps2)
     oracle.spectrum_add_cmplx_u8(1024, iq[0], ref2)
-    assert rel_err(ps2, ref2, EPS_K1).max() <= TOL
+    assert rel_err(ps2, ref2, EPS_STRICT).max() <= TOL_F64
     # len != N -> -1, buffer untouched (src/spectrum.c:51-52)
     before = ps.copy()
     assert s.add_cmplx_u8(iq[0][:1000], ps, length=1000) == -1
@@ -190,16 +209,80 @@ def test_dropin_accumulates_like_reference(built, oracle):
 
 def test_dropin_s32_f32_and_other_sizes(built, oracle):
     rng = np.random.default_rng(5)
-    for N in (2048, 4096, 512):
+    for N in (2048, 4096, 512, 1000, 8192, 2):
         s = built.Spectrum(N)
         x = rng.integers(-2000, 2000, size=(N, 2), dtype=np.int32)
         ps, ref = np.zeros(N), np.zeros(N)
         assert s.add_cmplx_s32(x, ps) == 0
         oracle.spectrum_add_cmplx_s32(N, x, ref)
-        assert rel_err(ps, ref, eps=EPS_K1).max() <= (1e-3 if N == 512 else TOL)
+        assert rel_err(ps, ref, EPS_STRICT).max() <= TOL_F64
         f = rng.standard_normal(N).astype(np.float32)
         ps, ref = np.zeros(N), np.zeros(N)
         assert s.add_real_f32(f, ps) == 0
         oracle.spectrum_add_real_f32(N, f, ref)
-        assert rel_err(ps, ref, eps=EPS_K1).max() <= (1e-3 if N == 512 else TOL)
+        assert rel_err(ps, ref, EPS_STRICT).max() <= TOL_F64
         s.free()
+    assert built.amd_lib().spectrum_alloc(8193) is None       # beyond the f64 kernel's LDS frame
+
+
+# ---- the f64 ("exact") kernel behind the reference-API paths --------------------
+
+@pytest.mark.parametrize("N,K", [(1024, 1), (1024, 6), (2048, 1), (4096, 8), (8192, 2), (2, 1), (4, 3),
+                                 (6, 2), (100, 1), (1000, 3), (1536, 2), (4099, 1)])
+def test_f64_batch_vs_oracle(engine, oracle, N, K):
+    """rtlws_spectra_batch_f64: radix-2 in LDS for powers of two, direct sum otherwise;
+    strict metric (eps = 1e-9) at 1e-10, K = 1 included."""
+    from rtlws import synth
+    nframes = 3 * K
+    for iq in (synth.tone_noise_iq(nframes, N, seed=N + K), synth.uniform_iq(nframes, N, seed=N - K + 7)):
+        got = engine.spectra(iq, N, k_avg=K, f64=True)
+        assert got.dtype == np.float64
+        ref = oracle.batch_spectra_u8(iq, N, K=K)
+        assert rel_err(got, ref, EPS_STRICT).max() <= TOL_F64, (N, K)
+    flat = np.full((K, N, 2), 128, dtype=np.uint8)
+    assert np.all(engine.spectra(flat, N, k_avg=K, f64=True) == 0.0)
+
+
+def test_f64_inputs_window_cic_and_epilogues(engine, oracle):
+    from rtlws import synth
+    rng = np.random.default_rng(12)
+    N = 1024
+    s32 = rng.integers(-4000, 4000, size=(3, N, 2), dtype=np.int32)
+    got = engine.spectra(s32, N, input="cs32", f64=True)
+    f32 = rng.standard_normal((3, N)).astype(np.float32)
+    gotf = engine.spectra(f32, N, input="rf32", f64=True)
+    for r in range(3):
+        ps = np.zeros(N)
+        oracle.spectrum_add_cmplx_s32(N, s32[r], ps)
+        assert rel_err(got[r], ps, EPS_STRICT).max() <= TOL_F64
+        ps = np.zeros(N)
+        oracle.spectrum_add_real_f32(N, f32[r], ps)
+        assert rel_err(gotf[r], ps, EPS_STRICT).max() <= TOL_F64
+    iq = synth.tone_noise_iq(16, 4096, seed=2)
+    got = engine.spectra(iq, 4096, k_avg=8, window="hann", f64=True)
+    ref = oracle.batch_spectra_u8(iq, 4096, K=8, window=synth.hann(4096))
+    assert rel_err(got, ref, EPS_STRICT).max() <= TOL_F64
+    iqc = synth.tone_noise_iq(4, 2048 * 10, seed=3)
+    got = engine.spectra(iqc, 2048, cic_r=10, k_avg=2, f64=True)
+    ref = oracle.batch_spectra_cic_u8(iqc, 2048, 10, K=2)
+    assert rel_err(got, ref, EPS_STRICT).max() <= TOL_F64
+    # epilogues in double: dB to 1e-11 dB, payload bytes IDENTICAL (src/cbb_main.c:112,125-128)
+    iq = synth.tone_noise_iq(12, 1024, seed=21)
+    ref = oracle.batch_spectra_u8(iq, 1024, K=6)
+    db = engine.spectra(iq, 1024, k_avg=6, output="mean_db", f64=True)
+    for r in range(2):
+        assert np.abs(db[r] - oracle.mean_db(ref[r], 6)).max() <= 1e-11
+    for gain in (0, 15, -25, 9, -9, 100):
+        pay = engine.spectra(iq, 1024, k_avg=6, output="payload_u8", gain_db=gain, f64=True)
+        for r in range(2):
+            assert np.array_equal(pay[r], oracle.spectrum_payload(ref[r], 6, gain)), gain
+
+
+def test_f64_bad_descriptors(engine, built):
+    iq = np.zeros((2, 1024, 2), dtype=np.uint8)
+    d_in = engine.upload(iq)
+    d_out = engine.alloc(2 * 1024 * 8)
+    assert engine.spectra_batch_f64(built.make_desc(1024, k_avg=3), d_in, 2, d_out, check=False) == -1
+    assert engine.spectra_batch_f64(built.make_desc(16384), d_in, 1, d_out, check=False) == -1
+    assert engine.spectra_batch_f64(built.make_desc(1024), d_in, 0, d_out, check=False) == 0
+    assert engine.spectra_batch_f64(built.make_desc(1024), d_in, 1, d_out.ptr + 4, check=False) == -1

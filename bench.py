@@ -2,27 +2,37 @@
 """bench.py -- spectra/s of the fused IQ -> power-spectrum hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: ONE launch of the fused
 kernel over 65 536 frames of 1024 cmplx_u8 (BASELINE.json configs[1]: 128 MiB
 of device-resident IQ in, 256 MiB of f32 power spectra out, K=1, rectangular
 window = reference behaviour).  Inputs are resident in HBM before the timed
 region; steps rotate over 4 buffer sets (1.5 GiB) so nothing is served from
-the 256 MiB Infinity Cache.  With N > 1 every rank runs the same batch on its
-own GPU (independent frames, no collective on the data path): weak scaling.
-The kernel runs at the package power cap, whose clock governor needs ~25 ms to
-settle: at least 500 untimed launches precede the timed region (W of them are
-the warm-up steps; the rest are reported as `settle_launches`).
+the 256 MiB Infinity Cache.  The kernel runs at the package power cap, whose
+clock governor needs ~25 ms to settle: at least 500 untimed launches precede
+the timed region (W of them are the warm-up steps; the rest are reported as
+`settle_launches`).
+
+N > 1: one process per GPU, every rank runs the same batch on its own device
+(independent frames, no collective on the data path): weak scaling.  Invoked
+directly with --gpus N > 1 (no WORLD_SIZE in the environment) this file starts
+the N ranks itself -- `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 bench.py ...` as a child process,
+before anything touches a GPU -- relays rank 0's JSON line and exits with the
+child's code; under torch.distributed.run it is a rank.
 
 One JSON line on stdout (rank 0).  `roofline` prices the kernel against HBM
-using the ALGORITHMIC bytes (2*N in + 4*N/K out per frame, SURVEY.md §8d);
+using the ALGORITHMIC bytes (2*N*R in + 4*N/K out per frame, SURVEY.md §8d);
 `cpu_baseline` times the f64 oracle (oracle/, kind "port") on this host's
-cores on a bounded sample of the same workload.
+cores -- one thread and all of the job's cores -- on a bounded sample of the
+same workload; `extra_workloads` carries the same measurement (fewer steps) for
+BASELINE.json configs[2] and configs[3] and the reference's own CIC factor.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +55,10 @@ WORKLOADS = {
     # 2*8*2048 bytes in, 8*2048 bytes out; unit reported: decimated samples/s
     "cic8_block_sums": (2048, 1, "rect", "cs32", 8, 8192),
 }
+HEADLINE = "batched_1024pt_64k_frames"
+# configs[2], configs[3] and the reference's own decimation factor ride along on the default line
+EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt")
+EXTRA_STEPS = 200
 
 
 def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum"):
@@ -59,7 +73,7 @@ def synth_iq_torch(torch, nframes, samples_per_frame, seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = torch.empty((nframes, samples_per_frame, 2), dtype=torch.uint8, device=device)
-    chunk = 4096
+    chunk = max(1, (1 << 24) // samples_per_frame)
     n = torch.arange(samples_per_frame, device=device, dtype=torch.float32)[None, :]
     for a in range(0, nframes, chunk):
         b = min(a + chunk, nframes)
@@ -109,17 +123,282 @@ def whole_job_rate(world, steps, frames_per_step, elapsed_s):
     return world * steps * frames_per_step / elapsed_s
 
 
-def main():
+# ---- N > 1 started directly: fan out into one rank per GPU -------------------
+
+def needs_fan_out(gpus, environ):
+    """True when this process was asked for N > 1 GPUs but is not itself a rank."""
+    return gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def fan_out(gpus, argv, plumbing_cpu=False):
+    """Start `gpus` ranks of this file under torch.distributed.run as a CHILD
+    process (nothing here has touched a GPU: torch.cuda.device_count() does not
+    initialise one on this image), relay rank 0's JSON line, return the child's
+    exit code.  Fewer devices than ranks is an error, not a smaller job."""
+    if not plumbing_cpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < gpus:
+            print("bench.py: --gpus %d but this host has %d HIP device(s); refusing to report a "
+                  "smaller job under that name" % (gpus, have), file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout.splitlines():
+        try:
+            if isinstance(json.loads(ln), dict):
+                line = ln
+        except ValueError:
+            sys.stderr.write(ln + "\n")          # anything else a rank wrote to stdout
+    if line is not None:
+        print(line, flush=True)
+    elif child.returncode == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return child.returncode
+
+
+# ---- one workload: settle, time K steps, price against HBM --------------------
+
+def parity_block(np, po, wl, host_in, got, nchk):
+    n_fft, k_avg, window, output, cic_r, _ = wl
+    if output == "cs32":
+        want = (host_in.astype(np.int32) - 128).reshape(-1, cic_r, 2).sum(axis=1).reshape(nchk, -1)
+        return {"frames": nchk, "bit_exact": bool(np.array_equal(got, want))}
+    got = got.astype(np.float64)
+    if cic_r > 1:
+        ref = po.batch_spectra_cic_u8(host_in, n_fft, cic_r, K=k_avg, nthreads=8)
+    else:
+        ref = po.batch_spectra_u8(host_in, n_fft, K=k_avg, nthreads=8,
+                                  window=None if window == "rect" else
+                                  (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)))
+    if output == "mean_db":
+        ref = 10 * np.log10(ref / k_avg)
+        return {"frames": nchk, "max_abs_db_err": float(np.abs(got - ref).max())}
+    mx = ref.max(axis=1, keepdims=True)
+    strict = np.abs(got - ref) / np.maximum(ref, 1e-9 * mx)
+    return {"frames": nchk,
+            "max_rel_err_floor1e-5": float((np.abs(got - ref) / np.maximum(ref, 1e-5 * mx)).max()),
+            "max_rel_err_floor1e-9": float(strict.max()),
+            "p99.9_rel_err_floor1e-9": float(np.percentile(strict, 99.9))}
+
+
+def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False):
+    """Allocate `sets` rotating buffer sets, run max(warmup, SETTLE_LAUNCHES)
+    untimed launches, time exactly `steps` launches between barrier +
+    synchronise on both sides (wall clock -> value) and between HIP events on
+    the launch stream (-> roofline), MAX over ranks.  Returns rank 0's dict."""
+    torch, np, rtlws, eng = ctx["torch"], ctx["np"], ctx["rtlws"], ctx["eng"]
+    dist, world, rank, device = ctx["dist"], ctx["world"], ctx["rank"], ctx["device"]
+    wl = WORKLOADS[name]
+    n_fft, k_avg, window, output, cic_r, frames = wl
+    if frames_override > 0:
+        frames = frames_override - frames_override % k_avg
+    spf = n_fft * max(cic_r, 1)
+    cic_only = (output == "cs32")
+    desc = None if cic_only else rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
+    rows = frames // k_avg
+
+    # device-resident inputs / outputs, allocated by torch (plumbing only)
+    ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(sets)]
+    out_dtype = torch.int32 if cic_only else torch.float32
+    out_cols = 2 * n_fft if cic_only else n_fft
+    outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
+    stream = torch.cuda.current_stream().cuda_stream
+    L = rtlws.hip_lib()
+
+    def step(i):
+        s = i % sets
+        if cic_only:
+            eng.cic_block_sums(cic_r, ins[s].data_ptr(), frames * n_fft, outs[s].data_ptr(), stream=stream)
+        else:
+            eng.spectra_batch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
+
+    # The kernels run at the package power cap and the clock governor needs
+    # ~300 launches (25 ms) to settle (DESIGN.md 4.1): whatever W is, at least
+    # SETTLE_LAUNCHES untimed launches precede the timed region.
+    settle = max(0, SETTLE_LAUNCHES - warmup)
+    for i in range(settle + warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    ev0, ev1 = L.rtlws_event_create(), L.rtlws_event_create()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    L.rtlws_event_record(ev0, eng.h, stream)
+    for i in range(steps):
+        step(i)
+    L.rtlws_event_record(ev1, eng.h, stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
+    L.rtlws_event_destroy(ev0)
+    L.rtlws_event_destroy(ev1)
+    elapsed, ev_ms = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
+
+    result = None
+    if rank == 0:
+        value = whole_job_rate(world, steps, frames, elapsed)
+        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output) * frames
+        avg_launch_s = (ev_ms / 1e3) / steps
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        if cic_only:
+            value *= n_fft                      # decimated samples per second
+        result = {
+            "metric": ("decimated samples/s (CIC R=%d)" % cic_r) if cic_only else
+                      ("spectra/s (1024-pt IQ frames)" if n_fft == 1024 else "spectra/s (%d-pt IQ frames)" % n_fft),
+            "value": value,
+            "unit": "samples/s" if cic_only else "spectra/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "settle_launches": settle,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32" if cic_only else "f32",
+            "data": "synthetic",
+            "config": {"workload": name, "n_fft": n_fft, "frames_per_step": frames,
+                       "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
+                       "input": "cmplx_u8 tone(0.6)+noise(0.05), device-resident, %d rotating sets" % sets,
+                       "sharding": "independent frames per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": 1e6 * avg_launch_s},
+        }
+
+        # parity spot check of what was just timed (first 256 rows of set 0)
+        from oracle import pyoracle as po
+        nchk = 256 * k_avg
+        host_in = ins[0][:nchk].cpu().numpy()
+        got = outs[0][:nchk if cic_only else 256].cpu().numpy()
+        result["parity"] = parity_block(np, po, wl, host_in, got, nchk)
+
+        if cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_block(np, po, wl, ins[0], frames)
+    del ins, outs
+    torch.cuda.empty_cache()
+    return result
+
+
+def cpu_baseline_block(np, po, wl, dev_in, frames):
+    """The f64 oracle on this host's cores over a bounded sample of buffer set 0:
+    one thread, then every core of the job's CPU share, ~3 s each."""
+    n_fft, k_avg, window, output, cic_r, _ = wl
+    nproc = os.cpu_count()
+    # the GPU box gives one GPU's job a 16-CPU share whatever nproc says
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    sample = min(frames, 16384 if n_fft <= 1024 else 4096)
+    sample -= sample % k_avg
+    host = dev_in[:sample].cpu().numpy()
+
+    def timed(nthreads, nframes, budget_s=3.0, max_reps=20):
+        h = host[:nframes]
+        reps, t_cpu = 0, 0.0
+        while t_cpu < budget_s and reps < max_reps:
+            c0 = time.perf_counter()
+            if cic_r > 1:
+                po.batch_spectra_cic_u8(h, n_fft, cic_r, K=k_avg, nthreads=nthreads)
+            else:
+                po.batch_spectra_u8(h, n_fft, K=k_avg, nthreads=nthreads)
+            t_cpu += time.perf_counter() - c0
+            reps += 1
+        return reps * nframes / t_cpu, reps
+
+    if output == "cs32":                       # one thread: the loop carries a dependency
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 3.0 and reps < 20:
+            c0 = time.perf_counter()
+            if po.ref_available():             # the reference's own object code (oracle/_ref)
+                po.ref_cic_decimate(cic_r, host.reshape(-1, 2))
+            else:
+                po.cic_decimate(cic_r, host.reshape(-1, 2))
+            t_cpu += time.perf_counter() - c0
+            reps += 1
+        return {"value": reps * sample * n_fft / t_cpu, "unit": "samples/s", "cores": 1, "nproc": nproc,
+                "kind": "reference" if po.ref_available() else "port",
+                "sample": "%d x %d decimated outputs of buffer set 0, %d repetitions, cic_decimate of %s"
+                          % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
+                             if po.ref_available() else "oracle/rtlws_oracle.c")}
+    one_n = max(k_avg, (sample // 8) - (sample // 8) % k_avg)
+    v1, reps1 = timed(1, one_n)
+    vall, repsall = timed(cores, sample)
+    return {"value": vall, "unit": "spectra/s", "cores": cores, "kind": "port", "nproc": nproc,
+            "one_thread": {"value": v1, "unit": "spectra/s", "cores": 1,
+                           "sample": "%d frames of buffer set 0, %d repetitions" % (one_n, reps1)},
+            "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
+                      "(oracle/rtlws_oracle.c) on %d pthreads; one_thread: the same code on 1"
+                      % (sample, frames, repsall, cores)}
+
+
+def plumbing_main(args):
+    """--plumbing-cpu (tests only): the rank plumbing of this file with the GPU step
+    replaced by a sleep -- rendezvous over gloo, barrier-bracketed timing, MAX over
+    ranks, whole-job rate, one JSON line from rank 0.  Measures nothing."""
+    import torch
+    dist, world, rank = init_distributed(torch, "gloo")
+    frames = WORKLOADS[args.workload][5]
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if dist is not None:
+        dist.barrier()
+    elapsed, slowest = max_over_ranks(torch, dist, [time.perf_counter() - t0, float(rank)])
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU step)", "value": whole_job_rate(world, args.steps, frames, elapsed),
+                          "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
+                          "slowest_rank": slowest, "asked_gpus": args.gpus, "data": "none"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if world == args.gpus else 3
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500,
                     help="untimed launches first; the clock governor needs ~300 (25 ms) to settle at the power cap")
-    ap.add_argument("--workload", default="batched_1024pt_64k_frames", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads on the default line")
     ap.add_argument("--frames", type=int, default=0, help="override frames per step (experiments)")
-    args = ap.parse_args()
+    ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+
+    if needs_fan_out(args.gpus, os.environ):
+        return fan_out(args.gpus, argv, args.plumbing_cpu)
+    if args.plumbing_cpu:
+        return plumbing_main(args)
 
     import numpy as np
     import torch
@@ -131,32 +410,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist, world, rank = init_distributed(torch, "nccl", device)
-
-    n_fft, k_avg, window, output, cic_r, frames = WORKLOADS[args.workload]
-    if args.frames > 0:
-        frames = args.frames - args.frames % k_avg
-    spf = n_fft * max(cic_r, 1)
-    eng = rtlws.Engine(local_rank)
-    cic_only = (output == "cs32")
-    desc = None if cic_only else rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
-    rows = frames // k_avg
     if args.gpus != world:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run); "
-              "reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    # device-resident inputs / outputs, allocated by torch (plumbing only)
-    ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(args.sets)]
-    out_dtype = torch.int32 if cic_only else torch.float32
-    out_cols = 2 * n_fft if cic_only else n_fft
-    outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(args.sets)]
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(i):
-        s = i % args.sets
-        if cic_only:
-            eng.cic_block_sums(cic_r, ins[s].data_ptr(), frames * n_fft, outs[s].data_ptr(), stream=stream)
-        else:
-            eng.spectra_batch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
+    eng = rtlws.Engine(local_rank)
+    ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
+           "rank": rank, "device": device}
 
     # First collective = RCCL's lazy communicator set-up (~16 ms): do it here, not
     # between the warm-up launches and the timed region, where that much idle
@@ -165,139 +424,28 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    # The kernels run at the package power cap and the clock governor needs
-    # ~300 launches (25 ms) to settle: whatever W is, at least
-    # SETTLE_LAUNCHES untimed launches precede the timed region.
-    settle = max(0, SETTLE_LAUNCHES - args.warmup)
-    for i in range(settle + args.warmup):
-        step(i)
-    torch.cuda.synchronize()
+    result = run_workload(ctx, args.workload, args.steps, args.warmup, args.sets, args.frames,
+                          cpu_baseline=(world == 1 and not args.no_cpu_baseline))
 
-    ev0, ev1 = rtlws.hip_lib().rtlws_event_create(), rtlws.hip_lib().rtlws_event_create()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rtlws.hip_lib().rtlws_event_record(ev0, eng.h, stream)
-    for i in range(args.steps):
-        step(i)
-    rtlws.hip_lib().rtlws_event_record(ev1, eng.h, stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    ev_ms = rtlws.hip_lib().rtlws_event_elapsed_ms(ev0, ev1)
+    # The default line also carries configs[2], configs[3] and the reference's own CIC
+    # factor, measured the same way with fewer steps (rank 0 of a 1-GPU job only).
+    if world == 1 and args.workload == HEADLINE and not args.no_extra and args.frames == 0:
+        extras = []
+        for name in EXTRA_WORKLOADS:
+            r = run_workload(ctx, name, EXTRA_STEPS, 0, args.sets)
+            extras.append({"workload": name, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                           "steps": r["steps"], "settle_launches": r["settle_launches"],
+                           "ms_per_step": r["ms_per_step"], "config": r["config"],
+                           "roofline": r["roofline"], "parity": r["parity"]})
+        result["extra_workloads"] = extras
 
-    elapsed, ev_ms = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
-
-    result = None
     if rank == 0:
-        value = whole_job_rate(world, args.steps, frames, elapsed)
-        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output) * frames
-        avg_launch_s = (ev_ms / 1e3) / args.steps
-        achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        if cic_only:
-            value *= n_fft                      # decimated samples per second
-        result = {
-            "metric": ("decimated samples/s (CIC R=%d)" % cic_r) if cic_only else
-                      ("spectra/s (1024-pt IQ frames)" if n_fft == 1024 else "spectra/s (%d-pt IQ frames)" % n_fft),
-            "value": value,
-            "unit": "samples/s" if cic_only else "spectra/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "settle_launches": settle,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int32" if cic_only else "f32",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "n_fft": n_fft, "frames_per_step": frames,
-                       "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
-                       "input": "cmplx_u8 tone(0.6)+noise(0.05), device-resident, %d rotating sets" % args.sets,
-                       "sharding": "independent frames per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": 1e6 * avg_launch_s},
-        }
-
-        # parity spot check of what was just timed (first 256 frames of set 0)
-        from oracle import pyoracle as po
-        nchk = 256 * k_avg
-        host_in = ins[0][:nchk].cpu().numpy()
-        got = outs[0][:256].cpu().numpy().astype(np.float64)
-        if cic_only:
-            want = (host_in.astype(np.int32) - 128).reshape(-1, cic_r, 2).sum(axis=1).reshape(nchk, -1)
-            result["parity"] = {"frames": nchk, "bit_exact": bool(np.array_equal(outs[0][:nchk].cpu().numpy(), want))}
-            ref = None
-        elif cic_r > 1:
-            ref = po.batch_spectra_cic_u8(host_in, n_fft, cic_r, K=k_avg, nthreads=8)
-        else:
-            ref = po.batch_spectra_u8(host_in, n_fft, K=k_avg, nthreads=8,
-                                      window=None if window == "rect" else
-                                      (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)))
-        if ref is None:
-            pass
-        elif output == "mean_db":
-            ref = 10 * np.log10(ref / k_avg)
-            result["parity"] = {"max_abs_db_err": float(np.abs(got - ref).max()), "frames": nchk}
-        else:
-            mx = ref.max(axis=1, keepdims=True)
-            result["parity"] = {
-                "frames": nchk,
-                "max_rel_err_floor1e-5": float((np.abs(got - ref) / np.maximum(ref, 1e-5 * mx)).max()),
-                "max_rel_err_floor1e-9": float((np.abs(got - ref) / np.maximum(ref, 1e-9 * mx)).max()),
-            }
-
-        if world == 1 and not args.no_cpu_baseline:
-            # the GPU box gives one GPU's job a 16-CPU share whatever nproc says
-            cores = min(len(os.sched_getaffinity(0)), 16)
-            sample = min(frames, 16384 if n_fft <= 1024 else 4096)
-            sample -= sample % k_avg
-            host = ins[0][:sample].cpu().numpy()
-            reps, t_cpu = 0, 0.0
-            while t_cpu < 3.0 and reps < 20:       # bounded: a few seconds of CPU work
-                c0 = time.perf_counter()
-                if cic_only:                   # one thread: the loop carries a dependency
-                    if po.ref_available():     # the reference's own object code (oracle/_ref)
-                        po.ref_cic_decimate(cic_r, host.reshape(-1, 2))
-                    else:
-                        po.cic_decimate(cic_r, host.reshape(-1, 2))
-                elif cic_r > 1:
-                    po.batch_spectra_cic_u8(host, n_fft, cic_r, K=k_avg, nthreads=cores)
-                else:
-                    po.batch_spectra_u8(host, n_fft, K=k_avg, nthreads=cores)
-                t_cpu += time.perf_counter() - c0
-                reps += 1
-            if cic_only:
-                result["cpu_baseline"] = {
-                    "value": reps * sample * n_fft / t_cpu, "unit": "samples/s", "cores": 1,
-                    "kind": "reference" if po.ref_available() else "port",
-                    "sample": "%d x %d decimated outputs of buffer set 0, %d repetitions, cic_decimate of %s"
-                              % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
-                                 if po.ref_available() else "oracle/rtlws_oracle.c")}
-            else:
-                result["cpu_baseline"] = {
-                    "value": reps * sample / t_cpu, "unit": "spectra/s", "cores": cores, "kind": "port",
-                    "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
-                              "(oracle/rtlws_oracle.c) on %d pthreads" % (sample, frames, reps, cores)}
         print(json.dumps(result), flush=True)
-
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return result
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

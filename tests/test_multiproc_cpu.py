@@ -65,3 +65,41 @@ def test_single_process_identity():
     assert bench.algorithmic_bytes_per_frame(1024, 1, 0) == 6144
     assert bench.algorithmic_bytes_per_frame(4096, 8, 0) == 10240
     assert bench.algorithmic_bytes_per_frame(2048, 1, 8) == 40960
+
+
+def test_bench_gpus_n_fans_out_by_itself():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it, no WORLD_SIZE):
+    the file starts its own two ranks as a child process and relays rank 0's line.
+    --plumbing-cpu swaps the GPU step for a sleep and RCCL for gloo, nothing else."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+                          "--plumbing-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout                      # the contract: ONE line on stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["asked_gpus"] == 2 and res["slowest_rank"] == 1.0
+    assert abs(res["value"] - 2 * 5 * 65536 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-9
+
+
+def test_bench_gpus_n_without_the_devices_fails_loudly():
+    """More GPUs asked for than the host has: non-zero exit and no result line --
+    never a silent n_gpus=1 under the name of an N-GPU run."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this host has the devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""
+    assert "--gpus 2" in out.stderr
+
+
+def test_fan_out_decision():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.needs_fan_out(2, {}) and bench.needs_fan_out(8, {"HOME": "/"})
+    assert not bench.needs_fan_out(1, {})
+    assert not bench.needs_fan_out(2, {"WORLD_SIZE": "2", "RANK": "0"})     # already a rank

@@ -88,5 +88,77 @@ __device__ __forceinline__ int2 cic_lane_sum(const uint8_t* piece, const CicLane
     return make_int2((int)si - c.bias, (int)sq - c.bias);
 }
 
+// Compile-time factor (the reference's own: sample_rate / 192000 = 10 at 2.048 MS/s,
+// 12 at 2.4 MS/s, src/main.c:23,154): the run of 2*RC bytes is read with fully
+// unrolled, conflict-free LDS loads and no scalar loop, no mask, no rotation.
+//   RC % 4 == 0: runs are 8-byte aligned -> RC/4 ds_read_b64; within a 32-lane
+//     group the lanes start at dword (RC/2)*l, and for RC = 12 the pairs
+//     {6l, 6l+1} mod 64 tile the 64 banks exactly once (gcd(3, 32) = 1).
+//   else (RC even): RC/2 ds_read_b32 at a lane stride of RC/2 dwords, odd for
+//     RC = 10 (5l mod 32 is a permutation of the banks).
+template <int RC>
+__device__ __forceinline__ int2 cic_lane_sum_ct(const uint8_t* piece, int lane)
+{
+    static_assert(RC >= 2 && RC % 2 == 0, "compile-time CIC factors are even");
+    unsigned si = 0u, sq = 0u;
+    if constexpr (RC % 4 == 0) {
+        const uint2* q = reinterpret_cast<const uint2*>(piece + lane * (2 * RC));
+#pragma unroll
+        for (int j = 0; j < RC / 4; ++j) {
+            const uint2 x = q[j];
+            si = __builtin_amdgcn_udot4(x.x, 0x00010001u, si, false);
+            sq = __builtin_amdgcn_udot4(x.x, 0x01000100u, sq, false);
+            si = __builtin_amdgcn_udot4(x.y, 0x00010001u, si, false);
+            sq = __builtin_amdgcn_udot4(x.y, 0x01000100u, sq, false);
+        }
+    } else {
+        const unsigned* q = reinterpret_cast<const unsigned*>(piece + lane * (2 * RC));
+#pragma unroll
+        for (int j = 0; j < RC / 2; ++j) {
+            const unsigned x = q[j];
+            si = __builtin_amdgcn_udot4(x, 0x00010001u, si, false);
+            sq = __builtin_amdgcn_udot4(x, 0x01000100u, sq, false);
+        }
+    }
+    return make_int2((int)si - 128 * RC, (int)sq - 128 * RC);
+}
+
+// cic_piece_to_lds with the factor known at compile time: the piece is
+// (128*RC) / 1024 1-KiB copies plus 256-byte copies, all unrolled.  One per-lane
+// address per access width; the position inside the piece is the instruction's
+// immediate offset, which the hardware adds to BOTH the global and the LDS
+// address (LDS = M0 base + offset + lane * width) -- no address arithmetic and
+// no M0 rewrite per copy.
+template <int OFF0, int I, int COUNT>
+__device__ __forceinline__ void cic_copies16_ct(const uint8_t* g, uint8_t* d)    // 1 KiB per copy
+{
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    if constexpr (I < COUNT) {
+        __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)d, 16, OFF0 + I * 1024, RTLWS_GLDS_AUX);
+        cic_copies16_ct<OFF0, I + 1, COUNT>(g, d);
+    }
+}
+template <int OFF0, int I, int COUNT>
+__device__ __forceinline__ void cic_copies4_ct(const uint8_t* g, uint8_t* d)     // 256 B per copy
+{
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    if constexpr (I < COUNT) {
+        __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)d, 4, OFF0 + I * 256, RTLWS_GLDS_AUX);
+        cic_copies4_ct<OFF0, I + 1, COUNT>(g, d);
+    }
+}
+
+template <int RC>
+__device__ __forceinline__ void cic_piece_to_lds_ct(const uint8_t* s, uint8_t* d, int lane)
+{
+    constexpr int chunk = 128 * RC;
+    constexpr int n16 = chunk >> 10, n4 = (chunk & 1023) >> 8;
+    static_assert((chunk & 255) == 0, "even factors only");
+    cic_copies16_ct<0, 0, n16>(s + lane * 16, d);
+    cic_copies4_ct<n16 * 1024, 0, n4>(s + lane * 4, d);
+}
+
 }  // namespace rtlws
 #endif

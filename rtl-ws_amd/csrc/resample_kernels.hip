@@ -46,10 +46,14 @@ __global__ __launch_bounds__(256) void cic8_kernel(const nt_u4* __restrict__ src
 // all G copies in flight together, then one 8-byte nontemporal store per lane
 // and piece.  The < 64 outputs that do not fill a piece are summed straight from
 // global memory by one wavefront.
+// RC: the factor as a compile-time constant (10, 12: the reference's own,
+// src/main.c:23,154 -- unrolled copies and conflict-free unrolled sums), or 0.
+template <int RC>
 __global__ __launch_bounds__(256) void cicr_kernel(const uint8_t* __restrict__ src,
-                                                   nt_i2* __restrict__ dst, long n, int R,
+                                                   nt_i2* __restrict__ dst, long n, int R_rt,
                                                    int slice_bytes, int G)
 {
+    const int R = RC ? RC : R_rt;
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];   // 4 wavefronts * slice_bytes
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -60,10 +64,15 @@ __global__ __launch_bounds__(256) void cicr_kernel(const uint8_t* __restrict__ s
     const CicLaneSum ls = cic_lane_setup(R, lane);
     for (long p0 = ((long)blockIdx.x * 4 + wave) * G; p0 < npieces; p0 += round_stride) {
         const int gn = (npieces - p0 < G) ? (int)(npieces - p0) : G;
-        for (int g = 0; g < gn; ++g) cic_piece_to_lds(src + (p0 + g) * chunk, my + g * chunk, R, lane);
+        for (int g = 0; g < gn; ++g) {
+            if constexpr (RC != 0) cic_piece_to_lds_ct<RC>(src + (p0 + g) * chunk, my + g * chunk, lane);
+            else cic_piece_to_lds(src + (p0 + g) * chunk, my + g * chunk, R, lane);
+        }
         cic_wait_pieces();
         for (int g = 0; g < gn; ++g) {
-            const int2 sum = cic_lane_sum(my + g * chunk, ls);
+            int2 sum;
+            if constexpr (RC != 0) sum = cic_lane_sum_ct<RC>(my + g * chunk, lane);
+            else sum = cic_lane_sum(my + g * chunk, ls);
             const nt_i2 o = {sum.x, sum.y};
             __builtin_nontemporal_store(o, dst + (p0 + g) * 64 + lane);
         }
@@ -105,9 +114,13 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
         const long cap = 256L * (slice == 8192 ? 4 : 2);
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(cicr_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * slice, st,
-                           reinterpret_cast<const uint8_t*>(d_src),
-                           reinterpret_cast<nt_i2*>(d_dst), dst_len, R, slice, G);
+        const uint8_t* s8 = reinterpret_cast<const uint8_t*>(d_src);
+        nt_i2* d2 = reinterpret_cast<nt_i2*>(d_dst);
+        const dim3 grid((unsigned)blocks), block(256);
+        const size_t lds = (size_t)4 * slice;
+        if (R == 10) hipLaunchKernelGGL(cicr_kernel<10>, grid, block, lds, st, s8, d2, dst_len, R, slice, G);
+        else if (R == 12) hipLaunchKernelGGL(cicr_kernel<12>, grid, block, lds, st, s8, d2, dst_len, R, slice, G);
+        else hipLaunchKernelGGL(cicr_kernel<0>, grid, block, lds, st, s8, d2, dst_len, R, slice, G);
     }
     return hipGetLastError();
 }

@@ -15,13 +15,17 @@ namespace rtlws {
 // a time.
 enum { IN_CU8 = 0, IN_CS32 = 1, IN_RF32 = 2, IN_CU8_CIC8 = 3,
        IN_CU8_CICR2 = 4, IN_CU8_CICR4 = 5, IN_CU8_CICR8 = 6, IN_CU8_CICR16 = 7,
-       IN_CU8_CICR_LDS4 = 8, IN_CU8_CICR_LDS2 = 9, IN_CU8_CICR_LDS1 = 10 };
+       IN_CU8_CICR_LDS4 = 8, IN_CU8_CICR_LDS2 = 9, IN_CU8_CICR_LDS1 = 10,
+       // the reference's own factors (sample_rate / 192000, src/main.c:23,154), staged
+       // through LDS like LDS4 but with the factor a compile-time constant
+       IN_CU8_CIC10 = 11, IN_CU8_CIC12 = 12 };
+constexpr int cic_ct_factor(int in_kind) { return in_kind == IN_CU8_CIC10 ? 10 : in_kind == IN_CU8_CIC12 ? 12 : 0; }
 
 // LDS staging of the CIC-fused input: each wavefront owns CICR_LDS_WAVE_BYTES of
 // the transposition buffer (fused_lds_f2 gives >= 9216 B per wavefront at every
 // N); a piece (64 samples) is 128R bytes.
 constexpr int CICR_LDS_WAVE_BYTES = 9216;
-constexpr int cicr_lds_round(int in_kind) { return in_kind == IN_CU8_CICR_LDS4 ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
+constexpr int cicr_lds_round(int in_kind) { return (in_kind == IN_CU8_CICR_LDS4 || in_kind >= IN_CU8_CIC10) ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
 constexpr int cicr_lds_max_r(int round) { return CICR_LDS_WAVE_BYTES / (round * 128); }   // 18, 36, 72
 
 // generic-R CIC input kind: per-lane direct loads by the alignment of a 2R-byte
@@ -34,6 +38,8 @@ constexpr int cicr_lds_kind(int R, int round)   // -1: does not fit
 }
 constexpr int cicr_kind(int R)
 {
+    if (R == 10) return IN_CU8_CIC10;
+    if (R == 12) return IN_CU8_CIC12;
     if (R < 3 || R > cicr_lds_max_r(1)) return cicr_direct_kind(R);
     return R <= cicr_lds_max_r(4) ? IN_CU8_CICR_LDS4 : R <= cicr_lds_max_r(2) ? IN_CU8_CICR_LDS2 : IN_CU8_CICR_LDS1;
 }
@@ -49,7 +55,8 @@ struct SpectraParams {
     int out_mode;          // OUT_*
     const float2* tw1;     // fused: [T][16] scale * W_N^(m1*rev16(s)); direct: [N] W_N^e
     const float2* tw2;     // fused: [16][R3/2] last-pass (cos, sin/cos) pairs of W_T^q2
-    const float* window;   // [N] or nullptr
+    const float* window;   // [N] or nullptr (direct kernel reads it; fused: only a flag)
+    const float2* hann_cs; // fused: [T] (0.5*cos, 0.5*sin)(2*pi*t/N), the lane constants of the generated Hann
     float db_offset;       // -10*log10(K)
     float lin_gain;        // gain / K for the payload epilogue
     float in_scale;        // 1/128 or 1 (fused: also folded into tw1[s >= 1])
@@ -88,9 +95,14 @@ struct SpectraParamsF64 {
 #ifndef RTLWS_WAVES_BIG
 #define RTLWS_WAVES_BIG 3
 #endif
+// input kinds that get a dedicated K == 1 instantiation (no accumulators)
+constexpr bool fused_kone_kind(int in_kind)
+{
+    return in_kind == IN_CU8 || in_kind == IN_CU8_CIC8 || in_kind >= IN_CU8_CIC10;
+}
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
-    const bool acc_and_prefetch = !kone && (in_kind == IN_CU8 || in_kind == IN_CU8_CIC8);
+    const bool acc_and_prefetch = !kone && fused_kone_kind(in_kind);
     return (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
            : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
            : RTLWS_WAVES_BIG;

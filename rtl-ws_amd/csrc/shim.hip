@@ -51,6 +51,7 @@ struct Tables {
     float2* tw1_128 = nullptr;      // fused: input scale 1/128 (u8, s32, CIC)
     float2* tw2 = nullptr;          // fused: last-pass (c, s/c) pairs
     float* hann = nullptr;
+    float2* hann_cs = nullptr;      // fused: [T] (0.5 cos, 0.5 sin)(2 pi t / N)
     double2* tw64 = nullptr;        // f64 kernel: W_N^k, k < N
     double* hann64 = nullptr;
 };
@@ -107,6 +108,7 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.tw1_128);
     (void)hipFree(tb.tw2);
     (void)hipFree(tb.hann);
+    (void)hipFree(tb.hann_cs);
     (void)hipFree(tb.tw64);
     (void)hipFree(tb.hann64);
     tb = Tables();
@@ -142,7 +144,13 @@ int get_tables(rtlws_engine* e, int n_fft, bool fused, Tables* out)
                     // alpha^(R3/L) * W_L^p = W_(T*L)^(q2*R3 + p*T)
                     h2[(size_t)q2 * NP + k++] = cos_tan_pair((long)q2 * R3 + (long)p * T, (long)T * L);
         }
-        if (!upload_table(h1, &tb.tw1) || !upload_table(h1s, &tb.tw1_128) || !upload_table(h2, &tb.tw2)) {
+        std::vector<float2> hcs((size_t)T);
+        for (int t = 0; t < T; ++t) {
+            const double a = kTwoPi * (double)t / (double)n_fft;
+            hcs[t] = make_float2((float)(0.5 * std::cos(a)), (float)(0.5 * std::sin(a)));
+        }
+        if (!upload_table(h1, &tb.tw1) || !upload_table(h1s, &tb.tw1_128) || !upload_table(h2, &tb.tw2) ||
+            !upload_table(hcs, &tb.hann_cs)) {
             free_tables(tb);
             return -3;
         }
@@ -465,7 +473,7 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
         int in_kind = d->input;
         if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
-                                           d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
+                                           d->k_avg == 1 && rtlws::fused_kone_kind(in_kind));
         if (threads) *threads = d->n_fft / 16;
         if (lds_bytes) *lds_bytes = (int)(sizeof(float2) * rtlws::fused_lds_f2(d->n_fft));
     } else {
@@ -509,6 +517,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     p.tw2 = tb.tw2;
     p.in_scale = scaled ? 0.0078125f : 1.0f;
     p.window = (d->window == RTLWS_WIN_HANN) ? tb.hann : nullptr;
+    p.hann_cs = tb.hann_cs;
     p.db_offset = (float)(-10.0 * std::log10((double)d->k_avg));
     // reference src/cbb_main.c:112: pow(10, gain_db/10) with C integer division
     p.lin_gain = (float)(std::pow(10.0, (double)(d->gain_db / 10)) / (double)d->k_avg);
@@ -521,7 +530,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     hipError_t err;
     if (fused) {
         const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
-                                        d->k_avg == 1 && (in_kind == rtlws::IN_CU8 || in_kind == rtlws::IN_CU8_CIC8));
+                                        d->k_avg == 1 && rtlws::fused_kone_kind(in_kind));
         switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
         case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;

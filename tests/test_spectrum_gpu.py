@@ -286,3 +286,22 @@ def test_f64_bad_descriptors(engine, built):
     assert engine.spectra_batch_f64(built.make_desc(16384), d_in, 1, d_out, check=False) == -1
     assert engine.spectra_batch_f64(built.make_desc(1024), d_in, 0, d_out, check=False) == 0
     assert engine.spectra_batch_f64(built.make_desc(1024), d_in, 1, d_out.ptr + 4, check=False) == -1
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("R", [10, 12])
+def test_cic_reference_factors_windowed_and_averaged(engine, oracle, N, R):
+    """The reference's own decimation factors (sample_rate / 192000: 10 at 2.048 MS/s, 12 at
+    2.4 MS/s, src/main.c:23,154) have compile-time input stages; every instantiation of
+    them (K = 1 / K > 1, rectangular / Hann, sum / dB) against the oracle."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(12, N * R, seed=31 * R + N // 512)
+    for K in (1, 4):
+        for window in ("rect", "hann"):
+            w = None if window == "rect" else synth.hann(N)
+            ref = oracle.batch_spectra_cic_u8(iq, N, R, K=K, window=w)
+            got = engine.spectra(iq, N, cic_r=R, k_avg=K, window=window)
+            assert rel_err(got, ref, EPS_K1).max() <= TOL, (N, R, K, window)
+    ref = oracle.batch_spectra_cic_u8(iq, N, R, K=4)
+    db = engine.spectra(iq, N, cic_r=R, k_avg=4, output="mean_db")
+    assert np.abs(db - 10 * np.log10(ref / 4)).max() <= 2e-4

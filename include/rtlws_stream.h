@@ -27,18 +27,21 @@ extern "C" {
 typedef struct rtlws_stream rtlws_stream;
 
 /* Called on the stream's worker thread, in push order, once a chunk's results
- * are in host memory.  `rows` points at rows_in_chunk * n_fft outputs (f32, or
+ * are in host memory (a chunk whose device work failed is counted in
+ * chunks_failed and NOT delivered).  `rows` points at rows_in_chunk * n_fft outputs (f32, or
  * bytes for RTLWS_OUT_PAYLOAD_U8) valid only during the call. */
 typedef void (*rtlws_stream_callback)(const void* rows, long nrows, long first_frame,
                                       double latency_ms, void* user);
 
 typedef struct rtlws_stream_stats {
     long chunks_pushed;
-    long chunks_done;
+    long chunks_done;          /* retired by the worker: delivered + failed in flight */
     long chunks_dropped;       /* rtlws_stream_push(..., block = 0) found the ring full */
-    long frames_done;
+    long frames_done;          /* frames whose rows reached the callback */
     double latency_ms_avg;     /* push -> results on the host */
     double latency_ms_max;
+    long chunks_failed;        /* device failure at enqueue (push returned -3) or in flight;
+                                  such a chunk is never handed to the callback */
 } rtlws_stream_stats;
 
 /* frames_per_chunk must be a multiple of desc->k_avg; ring_slots >= 2 chunks may

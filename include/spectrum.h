@@ -3,9 +3,10 @@
  *
  * Same five entry points, argument meaning and return codes as the reference
  * (reference src/spectrum.h:7-17, implemented by src/spectrum.c:37-107), but
- * implemented by librtlws_amd.so on an MI355X: u8/s32/f32 -> complex f32,
- * N-point forward FFT, |X|^2 and fft-shift all run in one HIP kernel
- * (rtl-ws_amd/csrc/spectrum_kernels.hip); only the accumulation into the
+ * implemented by librtlws_amd.so on an MI355X: u8/s32/f32 -> complex DOUBLE,
+ * N-point forward DFT, |X|^2 and fft-shift all run in one HIP kernel in the
+ * reference's own precision (rtl-ws_amd/csrc/spectrum_f64.hip, reached through
+ * rtlws_spectra_batch_f64 of rtlws_hip.h); only the accumulation into the
  * caller's host `double` buffer and the order-dependent DC-slot rule
  * (src/spectrum.c:25-33) stay on the calling thread, because that buffer is
  * host memory owned by the caller.
@@ -21,15 +22,19 @@
  *   - Synchronous: the result is in `power_spectrum` on return.
  *
  * Differences, stated so a maintainer is not surprised:
- *   - N must be 1024, 2048 or 4096 for the fused kernel; any other N >= 2 is
- *     served by a slower direct-DFT kernel on the GPU.  There is no CPU path:
- *     if no HIP device is usable spectrum_alloc returns NULL (the reference
- *     never reports failure).
- *   - Arithmetic is f32 on the device (reference: f64 via FFTW); measured
- *     agreement is in DESIGN.md.
+ *   - 2 <= N <= 8192 (a frame lives in the 160 KiB LDS of one compute unit as
+ *     complex doubles): radix-2 for powers of two, a direct O(N^2) sum for any
+ *     other N.  There is no CPU path: if no HIP device is usable, or N is out of
+ *     range, spectrum_alloc returns NULL (the reference never reports failure).
+ *   - Arithmetic is f64 on the device, like the reference (f64 via FFTW):
+ *     increments agree with an f64 FFT to <= 1e-10 relative per bin under the
+ *     strict metric (floor 1e-9 of the row maximum), K = 1 included
+ *     (tests/test_spectrum_gpu.py::test_dropin_*).  The summation order inside
+ *     the transform differs from FFTW's, so the last bits do.
  *
- * For throughput use the batch API in rtlws_hip.h: this one moves at most
- * N samples per call across PCIe.
+ * For throughput use the batch API in rtlws_hip.h (rtlws_spectra_batch: f32
+ * arithmetic, device-resident frames, its own stated error budget): this one
+ * moves at most N samples per call across PCIe.
  */
 #ifndef SPECTRUM_H
 #define SPECTRUM_H

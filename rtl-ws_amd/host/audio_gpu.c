@@ -56,9 +56,12 @@ void audio_init(void)
         g_d_phase = (float*)rtlws_dev_alloc(g_eng, 2 * sizeof(float));
         rtlws_memset_dev(g_eng, g_d_phase, 0, 2 * sizeof(float), NULL);
         rtlws_stream_sync(g_eng, NULL);
+        g_len = 0;
+        g_phase_idx = 0;
     }
-    g_len = 0;
-    g_phase_idx = 0;
+    /* a second audio_init without audio_close only restarts the queue: the phase
+     * carry, the delay lines and the block length are function statics in the
+     * reference (src/audio_main.c:76-79) and survive there, so they survive here */
     g_q_head = g_q_count = g_read_pos = 0;
     pthread_mutex_unlock(&g_mu);
 }
@@ -122,7 +125,7 @@ static int resize_for(int len)
 void audio_fm_demodulator(const cmplx_s32* signal, int len)
 {
     const int half = len / 2, quarter = half / 2;
-    int rc = 0;
+    int rc = 0, have_buf;
     if (len <= 0) return;
     pthread_mutex_lock(&g_mu);
     if (!g_eng) { pthread_mutex_unlock(&g_mu); fprintf(stderr, "rtlws: audio_fm_demodulator before audio_init\n"); abort(); }
@@ -143,6 +146,10 @@ void audio_fm_demodulator(const cmplx_s32* signal, int len)
             rtlws_stream_sync(g_eng, NULL);
         }
     }
+    /* reference src/audio_main.c:137-142: the second half-band runs -- and its delay
+     * line advances -- only when a pool buffer is free to take its output; a
+     * block that meets an exhausted pool leaves delay line 2 untouched */
+    have_buf = g_q_count < AUDIO_BUFFER_POOL;
     if (!rc) {
         float* prev_in = g_d_phase + g_phase_idx;
         float* prev_out = g_d_phase + (1 - g_phase_idx);
@@ -150,11 +157,12 @@ void audio_fm_demodulator(const cmplx_s32* signal, int len)
         if (rtlws_copy_h2d(g_eng, g_d_iq, g_h_iq, (size_t)len * sizeof(cmplx_s32), NULL) ||
             rtlws_fm_demod(g_eng, g_d_iq, len, prev_in, prev_out, g_d_demod + HIST, NULL) ||
             rtlws_halfband(g_eng, g_d_demod, g_d_work + HIST, half, NULL) ||              /* :133 */
-            rtlws_halfband(g_eng, g_d_work, g_d_audio, quarter, NULL) ||                  /* :139 */
-            /* delay lines <- last 10 inputs of each stage (src/resample.c:66) */
+            /* delay line 1 <- last 10 inputs of the stage (src/resample.c:66) */
             rtlws_copy_d2d(g_eng, g_d_demod, g_d_demod + 2 * half, HIST * sizeof(float), NULL) ||
-            rtlws_copy_d2d(g_eng, g_d_work, g_d_work + 2 * quarter, HIST * sizeof(float), NULL) ||
-            rtlws_copy_d2h(g_eng, g_h_audio, g_d_audio, (size_t)quarter * sizeof(float), NULL) ||
+            (have_buf &&
+             (rtlws_halfband(g_eng, g_d_work, g_d_audio, quarter, NULL) ||               /* :139 */
+              rtlws_copy_d2d(g_eng, g_d_work, g_d_work + 2 * quarter, HIST * sizeof(float), NULL) ||
+              rtlws_copy_d2h(g_eng, g_h_audio, g_d_audio, (size_t)quarter * sizeof(float), NULL))) ||
             rtlws_stream_sync(g_eng, NULL))
             rc = -3;
         else
@@ -165,7 +173,7 @@ void audio_fm_demodulator(const cmplx_s32* signal, int len)
         fprintf(stderr, "rtlws: audio_fm_demodulator: device failure: %s\n", rtlws_last_error());
         abort();                      /* void signature: fail loudly */
     }
-    if (g_q_count < AUDIO_BUFFER_POOL && quarter > 0) {   /* pool exhausted: drop, as :137-142 */
+    if (have_buf && quarter > 0) {
         float* dst = g_pool[(g_q_head + g_q_count) % AUDIO_BUFFER_POOL];
         memcpy(dst, g_h_audio, (size_t)quarter * sizeof(float));
         g_q_count++;

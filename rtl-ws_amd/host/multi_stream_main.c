@@ -95,7 +95,7 @@ int main(int argc, char** argv)
     struct producer* ps;
     pthread_t* th;
     double total_rate = 0.0, lat_max = 0.0, lat_avg = 0.0;
-    long drops = 0, frames = 0;
+    long drops = 0, failed = 0, frames = 0;
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seconds") && i + 1 < argc) seconds = atof(argv[++i]);
@@ -125,15 +125,16 @@ int main(int argc, char** argv)
     for (i = 0; i < streams; i++) {
         if (ps[i].elapsed_s > 0) total_rate += (double)ps[i].stats.frames_done / ps[i].elapsed_s;
         drops += ps[i].stats.chunks_dropped;
+        failed += ps[i].stats.chunks_failed;
         frames += ps[i].stats.frames_done;
         lat_avg += ps[i].stats.latency_ms_avg / streams;
         if (ps[i].stats.latency_ms_max > lat_max) lat_max = ps[i].stats.latency_ms_max;
     }
     printf("{\"streams\": %d, \"devices\": %d, \"paced\": %s, \"rate_hz\": %.0f, \"n_fft\": %d, \"k_avg\": %d, "
            "\"seconds\": %.2f, \"spectra_per_s_total\": %.1f, \"spectra_per_s_per_stream\": %.1f, "
-           "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}\n",
+           "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}\n",
            streams, ndev, unpaced ? "false" : "true", rate, nfft, k, seconds, total_rate,
-           total_rate / streams, frames, drops, lat_avg, lat_max);
+           total_rate / streams, frames, drops, failed, lat_avg, lat_max);
     free(ps);
     free(th);
     return 0;

@@ -64,6 +64,7 @@ static void* worker_main(void* arg)
     for (;;) {
         struct slot* sl;
         double lat;
+        int failed;
         pthread_mutex_lock(&s->mu);
         while (!s->closing && s->slots[s->tail].state != SLOT_IN_FLIGHT)
             pthread_cond_wait(&s->cv_work, &s->mu);
@@ -74,18 +75,24 @@ static void* worker_main(void* arg)
         sl = &s->slots[s->tail];
         pthread_mutex_unlock(&s->mu);
 
-        if (rtlws_event_sync(sl->done) != 0)
-            fprintf(stderr, "rtlws_stream: device failure: %s\n", rtlws_last_error());
+        /* a chunk whose device work failed has no valid rows: it is counted, never
+         * delivered (h_out holds stale or partial data) */
+        failed = rtlws_event_sync(sl->done) != 0;
+        if (failed) fprintf(stderr, "rtlws_stream: device failure: %s\n", rtlws_last_error());
         lat = now_ms() - sl->t_push_ms;
-        if (s->cb) s->cb(sl->h_out, s->rows_per_chunk, sl->first_frame, lat, s->user);
+        if (s->cb && !failed) s->cb(sl->h_out, s->rows_per_chunk, sl->first_frame, lat, s->user);
 
         pthread_mutex_lock(&s->mu);
         sl->state = SLOT_FREE;
         s->tail = (s->tail + 1) % s->nslots;
-        s->st.chunks_done++;
-        s->st.frames_done += s->frames_per_chunk;
-        s->lat_sum += lat;
-        if (lat > s->st.latency_ms_max) s->st.latency_ms_max = lat;
+        s->st.chunks_done++;                      /* retired: delivered or failed */
+        if (failed) {
+            s->st.chunks_failed++;
+        } else {
+            s->st.frames_done += s->frames_per_chunk;
+            s->lat_sum += lat;
+            if (lat > s->st.latency_ms_max) s->st.latency_ms_max = lat;
+        }
         pthread_cond_broadcast(&s->cv_free);
         pthread_mutex_unlock(&s->mu);
     }
@@ -159,6 +166,12 @@ int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block)
         rtlws_spectra_batch(s->eng, &s->desc, sl->d_in, s->frames_per_chunk, sl->d_out, NULL) ||
         rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, NULL) ||
         rtlws_event_record(sl->done, s->eng, NULL)) {
+        /* part of the chain may already be queued against this slot's buffers, and
+         * the slot stays FREE: drain the queue so that the next push cannot
+         * overwrite h_in / d_in under a copy or a kernel still in flight */
+        rtlws_stream_sync(s->eng, NULL);
+        s->st.chunks_failed++;
+        s->next_frame += s->frames_per_chunk;          /* the lost frames keep their numbers */
         rc = -3;
     } else {
         sl->state = SLOT_IN_FLIGHT;
@@ -184,7 +197,10 @@ void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out)
 {
     pthread_mutex_lock(&s->mu);
     *out = s->st;
-    out->latency_ms_avg = s->st.chunks_done ? s->lat_sum / (double)s->st.chunks_done : 0.0;
+    {
+        const long delivered = s->st.frames_done / s->frames_per_chunk;
+        out->latency_ms_avg = delivered ? s->lat_sum / (double)delivered : 0.0;
+    }
     pthread_mutex_unlock(&s->mu);
 }
 

@@ -267,3 +267,33 @@ def test_fm_demod_difference_and_limit(oracle):
     assert out[1] == 1.0 and out[2] == 1.0        # +pi/2 steps are limited to +1
     assert out[3] == -1.0                         # the wrap from +pi to ~0 is limited to -1
     assert abs(out[4] - 0.01) < 1e-3 and abs(prev - 0.02) < 1e-3
+
+
+def test_header_atan2_approx_matches_the_pinned_restatement(tmp_path, oracle):
+    """include/common_sp.h carries atan2_approx for reference units that stay in the build
+    (src/audio_main.c); it must agree bit for bit with the oracle's, which is pinned to the
+    reference's object code through tests/golden/audio_ref.npz."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "a.c"
+    src.write_text('#include "common_sp.h"\nfloat hdr_atan2(float y, float x) { return atan2_approx(y, x); }\n'
+                   'int hdr_macros(void) { cmplx_u8 a; cmplx_s32 s, t, r; set_cmplx_u8(a, 200, 3);\n'
+                   '  set_cmplx_s32_cmplx_u8(s, a, -128); set_cmplx_s32(t, s); add_cmplx_s32(s, t, r);\n'
+                   '  sub_cmplx_s32(r, t, r); return real_cmplx_s32(r) * 1000 + imag_cmplx_s32(r)\n'
+                   '  + real_cmplx_u8(a) * 1000000 + imag_cmplx_u8(a) * 100000000; }\n')
+    so = tmp_path / "a.so"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(root, "include"),
+                    "-o", str(so), str(src), "-lm"], check=True)
+    L = ctypes.CDLL(str(so))
+    L.hdr_atan2.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.hdr_atan2.restype = ctypes.c_float
+    rng = np.random.default_rng(3)
+    pts = [(0, 0), (1, 0), (-1, 0), (0, 1), (0, -1), (5, 5), (-5, 5), (5, -5), (-5, -5), (1, -3), (-1, -3)]
+    pts += [tuple(v) for v in rng.integers(-3000, 3000, size=(4000, 2))]
+    for y, x in pts:
+        a, b = L.hdr_atan2(float(y), float(x)), oracle.atan2_approx(float(y), float(x))
+        assert np.float32(a).tobytes() == np.float32(b).tobytes(), (y, x, a, b)
+    # (200-128) = 72, (3-128) = -125: s = (72,-125); r = s + s - s
+    assert L.hdr_macros() == 72 * 1000 - 125 + 200 * 1000000 + 3 * 100000000

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 class Stats(C.Structure):
     _fields_ = [("chunks_pushed", C.c_long), ("chunks_done", C.c_long), ("chunks_dropped", C.c_long),
-                ("frames_done", C.c_long), ("latency_ms_avg", C.c_double), ("latency_ms_max", C.c_double)]
+                ("frames_done", C.c_long), ("latency_ms_avg", C.c_double), ("latency_ms_max", C.c_double),
+                ("chunks_failed", C.c_long)]
 
 
 CB = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long, C.c_double, C.c_void_p)
@@ -81,7 +82,7 @@ def test_stream_drops_when_ring_is_full_and_not_blocking(built):
     L.rtlws_stream_get_stats(s, C.byref(st))
     L.rtlws_stream_close(s)
     assert set(rcs) <= {0, 1} and rcs.count(1) == st.chunks_dropped > 0
-    assert st.chunks_done == st.chunks_pushed == rcs.count(0)
+    assert st.chunks_done == st.chunks_pushed == rcs.count(0) and st.chunks_failed == 0
 
 
 def test_bad_open_arguments(built):
@@ -95,13 +96,14 @@ def test_bad_open_arguments(built):
 
 
 def test_multi_stream_driver_realtime_no_drops(built):
-    """configs[4] on the one GPU this box has: 4 paced 2.4 MS/s streams share device 0."""
+    """configs[4]'s stream count on the one GPU this box has: 8 paced 2.4 MS/s streams
+    (stream i -> device i mod n_devices, so all eight share device 0 here)."""
     exe = os.path.join(built.LIB_DIR, "rtlws_multi_stream")
-    out = subprocess.run([exe, "--streams", "4", "--seconds", "1.5", "--rate", "2400000"],
+    out = subprocess.run([exe, "--streams", "8", "--seconds", "1.5", "--rate", "2400000"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["chunks_dropped"] == 0
+    assert r["streams"] == 8 and r["chunks_dropped"] == 0 and r["chunks_failed"] == 0
     # 2.4 MS/s / 1024 = 2343.75 spectra/s per stream
     assert 0.9 * 2343.75 < r["spectra_per_s_per_stream"] < 1.1 * 2343.75
     assert r["latency_ms_avg"] < 20 and r["latency_ms_max"] < 1000     # max includes the cold first launch

@@ -25,7 +25,16 @@ constexpr int cic_ct_factor(int in_kind) { return in_kind == IN_CU8_CIC10 ? 10 :
 // the transposition buffer (fused_lds_f2 gives >= 9216 B per wavefront at every
 // N); a piece (64 samples) is 128R bytes.
 constexpr int CICR_LDS_WAVE_BYTES = 9216;
-constexpr int cicr_lds_round(int in_kind) { return (in_kind == IN_CU8_CICR_LDS4 || in_kind >= IN_CU8_CIC10) ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
+// pieces in flight per round for the compile-time factors (experiments: -DRTLWS_CIC_CT_ROUND=8)
+#ifndef RTLWS_CIC_CT_ROUND
+#define RTLWS_CIC_CT_ROUND 4
+#endif
+constexpr int cicr_lds_round(int in_kind) { return in_kind >= IN_CU8_CIC10 ? RTLWS_CIC_CT_ROUND : in_kind == IN_CU8_CICR_LDS4 ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
+// bytes of LDS one wavefront stages its round in
+constexpr int cic_stage_wave_bytes(int in_kind)
+{
+    return cic_ct_factor(in_kind) ? cicr_lds_round(in_kind) * 128 * cic_ct_factor(in_kind) : CICR_LDS_WAVE_BYTES;
+}
 constexpr int cicr_lds_max_r(int round) { return CICR_LDS_WAVE_BYTES / (round * 128); }   // 18, 36, 72
 
 // generic-R CIC input kind: per-lane direct loads by the alignment of a 2R-byte
@@ -100,12 +109,17 @@ constexpr bool fused_kone_kind(int in_kind)
 {
     return in_kind == IN_CU8 || in_kind == IN_CU8_CIC8 || in_kind >= IN_CU8_CIC10;
 }
+constexpr int fused_lds_f2(int n_fft);
+constexpr int fused_lds_bytes(int n_fft, int in_kind);
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
     const bool acc_and_prefetch = !kone && fused_kone_kind(in_kind);
-    return (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
-           : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
-           : RTLWS_WAVES_BIG;
+    const int by_regs = (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
+                        : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
+                        : RTLWS_WAVES_BIG;
+    // workgroups per CU that fit the 160 KiB LDS, n_fft/1024 wavefronts each, over 4 SIMDs
+    const int by_lds = (163840 / fused_lds_bytes(n_fft, in_kind)) * (n_fft / 1024) / 4;
+    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 
 // One-frame-ahead prefetch of the raw cmplx_u8 bytes (16 VGPRs).  Worth <= 2 % at
@@ -118,6 +132,13 @@ constexpr bool fused_prefetch_u8(int n_fft, bool win) { return !(n_fft == 4096 &
 constexpr int fused_lds_f2(int n_fft)
 {
     return 16 * 18 * (n_fft / 256) + 2;     // transposition 2 is the larger of the two
+}
+// ... in bytes, by input kind: the CIC staging slices share the buffer and may be the larger need
+constexpr int fused_lds_bytes(int n_fft, int in_kind)
+{
+    const int tr = 8 * fused_lds_f2(n_fft);
+    const int st = in_kind >= IN_CU8_CICR_LDS4 ? (n_fft / 1024) * cic_stage_wave_bytes(in_kind) : 0;
+    return st > tr ? st : tr;
 }
 
 hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);

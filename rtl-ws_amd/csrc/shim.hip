@@ -475,7 +475,7 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
                                            d->k_avg == 1 && rtlws::fused_kone_kind(in_kind));
         if (threads) *threads = d->n_fft / 16;
-        if (lds_bytes) *lds_bytes = (int)(sizeof(float2) * rtlws::fused_lds_f2(d->n_fft));
+        if (lds_bytes) *lds_bytes = rtlws::fused_lds_bytes(d->n_fft, in_kind);
     } else {
         if (blocks) *blocks = (int)ngroups;
         if (threads) *threads = 256;

@@ -10,7 +10,7 @@ properties (every row checked) plus the oracle on a random subsample.
 import numpy as np
 import pytest
 
-from helpers import rel_err, EPS_K1, EPS_STRICT, TOL
+from helpers import rel_err, strict_stats, EPS_K1, EPS_STRICT, TOL, STRICT_K1_P999, STRICT_K1_MAX
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,8 @@ def test_config2_65536_frames_of_1024(engine, oracle):
     rows = rng.choice(nframes, size=768, replace=False)
     ref = oracle.batch_spectra_u8(iq[rows], N, nthreads=8)
     assert rel_err(got[rows], ref, EPS_K1).max() <= TOL
+    mx, p999 = strict_stats(got[rows], ref)          # strict floor (1e-9) guard, K = 1
+    assert mx <= STRICT_K1_MAX and p999 <= STRICT_K1_P999, (mx, p999)
 
 
 def test_config3_16384_frames_of_4096_hann_k8(engine, oracle):
@@ -93,6 +95,8 @@ def test_config4_8192_spectra_cic8_2048(engine, oracle):
     rows = rng.choice(nspec, size=96, replace=False)
     ref = oracle.batch_spectra_cic_u8(iq[rows], N, R, nthreads=8)
     assert rel_err(got[rows], ref, EPS_K1).max() <= TOL
+    mx, p999 = strict_stats(got[rows], ref)          # strict floor (1e-9) guard, K = 1
+    assert mx <= STRICT_K1_MAX and p999 <= STRICT_K1_P999, (mx, p999)
     # the CIC on its own, bit-exact on the whole 256 MiB input
     d_src = engine.upload(iq)
     d_dst = engine.alloc(nspec * N * 8)

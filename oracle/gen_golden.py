@@ -26,6 +26,16 @@ Two kinds of vector, told apart by the `source` field in each file:
         payload_oracle.npz    dB payload bytes for gains {0,15,-25},
                               blocks {0,2,6}
 
+  source = "fftw3_via_scipy_test_data"
+      fftw_dct2_dst2.npz: outputs of the real FFTW3 library (REDFT10 / RODFT10 of
+      x = 0..n-1, n in {2,3,4,8,12,15,16,17,32,...,1024}), extracted from the
+      reference data SciPy ships for its own tests
+      (scipy/fftpack/tests/fftw_double_ref.npz, produced by its gen_fftw_ref.py
+      with FFTW).  FFTW3 is the library src/spectrum.c:21,42 calls and is absent
+      from this image; these are the only FFTW-computed numbers in it.  They pin
+      the oracle's DFT -- magnitude AND the forward sign convention, through the
+      sine transform -- by the identities in tests/test_oracle_cpu.py.
+
 Only data (inputs + expected outputs) is written; no reference source text.
 """
 import os
@@ -163,8 +173,25 @@ def gen_oracle_vectors():
     np.savez_compressed(os.path.join(OUT, "payload_oracle.npz"), **d)
 
 
+def gen_fftw_vectors():
+    """FFTW-computed DCT-II / DST-II vectors out of SciPy's own test data (see the
+    module docstring); skipped when this SciPy build does not ship them."""
+    import scipy.fftpack
+    src = os.path.join(os.path.dirname(scipy.fftpack.__file__), "tests", "fftw_double_ref.npz")
+    if not os.path.exists(src):
+        print("scipy fftw_double_ref.npz not found: keeping tests/golden/fftw_dct2_dst2.npz")
+        return
+    ref = np.load(src)
+    d = {"source": "fftw3_via_scipy_test_data", "sizes": np.asarray(ref["sizes"])}
+    for n in ref["sizes"]:
+        d["dct2_%d" % n] = ref["dct_2_%d" % n]
+        d["dst2_%d" % n] = ref["dst_2_%d" % n]
+    np.savez_compressed(os.path.join(OUT, "fftw_dct2_dst2.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_fftw_vectors()
     po.build()
     gen_reference_vectors()
     gen_audio_vectors()

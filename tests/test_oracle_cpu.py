@@ -297,3 +297,31 @@ def test_header_atan2_approx_matches_the_pinned_restatement(tmp_path, oracle):
         assert np.float32(a).tobytes() == np.float32(b).tobytes(), (y, x, a, b)
     # (200-128) = 72, (3-128) = -125: s = (72,-125); r = s + s - s
     assert L.hdr_macros() == 72 * 1000 - 125 + 200 * 1000000 + 3 * 100000000
+
+
+def test_oracle_dft_reproduces_fftw_computed_vectors(oracle):
+    """The only FFTW3-computed numbers in this image: DCT-II / DST-II (REDFT10 / RODFT10)
+    of x = 0..n-1 from SciPy's own test data (tests/golden/fftw_dct2_dst2.npz,
+    oracle/gen_golden.py).  With z[2j+1] = x_j, z[4n-2j-1] = +-x_j (length 4n) the forward
+    DFT gives  Re Z_k = 2 sum x_j cos(pi (j+1/2) k / n)      = REDFT10[k]      (even z)
+               -Im Z_k = 2 sum x_j sin(pi (j+1/2) k / n)     = RODFT10[k-1]    (odd z)
+    -- the second fixes the SIGN of the exponent (forward = exp(-2 pi i nk/N), what
+    fftw_plan_dft_1d(..., FFTW_FORWARD, ...) of src/spectrum.c:42 computes): a +i DFT
+    would return the sine transform negated.  4n runs to 4096: the oracle's radix-2 path
+    and (n = 3, 12, 15, 17) its direct path."""
+    g = golden("fftw_dct2_dst2.npz")
+    assert str(g["source"]) == "fftw3_via_scipy_test_data"
+    for n in g["sizes"]:
+        n = int(n)
+        x = np.linspace(0, n - 1, n)
+        for name, sgn in (("dct2", 1.0), ("dst2", -1.0)):
+            z = np.zeros(4 * n, dtype=np.complex128)
+            z[1:2 * n:2] = x
+            z[4 * n - 1:2 * n:-2] = sgn * x
+            Z = oracle.dft(z)
+            got = Z.real[:n] if name == "dct2" else -Z.imag[1:n + 1]
+            want = g["%s_%d" % (name, n)]
+            assert np.abs(got - want).max() <= 2e-15 * np.abs(want).max(), (name, n)
+            # and the part that must vanish does (even z -> real spectrum, odd z -> imaginary)
+            other = Z.imag if name == "dct2" else Z.real
+            assert np.abs(other).max() <= 2e-13 * max(np.abs(want).max(), 1.0)

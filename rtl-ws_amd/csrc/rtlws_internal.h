@@ -128,7 +128,10 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 // One-frame-ahead prefetch of the raw cmplx_u8 bytes (16 VGPRs).  Worth <= 2 % at
 // 12-16 resident wavefronts per CU; the windowed 4096-point kernels have no
 // room for it at 168 VGPRs, so they load in the loop instead of spilling.
-constexpr bool fused_prefetch_u8(int n_fft, bool win) { return !(n_fft == 4096 && win); }
+#ifndef RTLWS_PREFETCH_4096WIN
+#define RTLWS_PREFETCH_4096WIN 0
+#endif
+constexpr bool fused_prefetch_u8(int n_fft, bool win) { return RTLWS_PREFETCH_4096WIN || !(n_fft == 4096 && win); }
 
 // LDS the fused kernel needs, in float2 units: 16 (padded) rows + one spare slot
 // (layouts: spectrum_fused.hip, "LDS layouts").

@@ -87,3 +87,46 @@ def test_decimator_to_audio_pipeline(built, oracle):
         rc, dec, _ = oracle.cic_decimate(R, iq[b * 8192:(b + 1) * 8192])
         want.append(oracle.audio_block(dec, st))
     assert np.array_equal(got, np.concatenate(want))
+
+
+def test_pool_exhaustion_leaves_delay_line_2_untouched(built, oracle):
+    """reference src/audio_main.c:137-142: when none of the 50 pool buffers is free the
+    block is dropped BEFORE the second half-band, so delay line 2 keeps the state of the
+    last queued block while the phase carry and delay line 1 (first half-band, :133) keep
+    advancing.  50 blocks fill the pool, 3 more are dropped, the pool is drained, and the
+    54th block must come out as the oracle computes it from exactly that mixed state."""
+    rng = np.random.default_rng(5)
+    n, pool = 512, 50
+    blocks = [rng.integers(-2000, 2000, size=(n, 2), dtype=np.int32) for _ in range(pool + 4)]
+    L = built.amd_lib()
+    L.audio_get_audio_payload.argtypes = [C.c_void_p, C.c_int]
+    L.audio_fm_demodulator.argtypes = [C.c_void_p, C.c_int]
+    st = np.zeros(21, dtype=np.float32)
+    want = []
+    for k, b in enumerate(blocks):
+        keep = st[11:21].copy()
+        out = oracle.audio_block(b, st)
+        if pool <= k < pool + 3:
+            st[11:21] = keep                  # dropped: second half-band never ran
+        else:
+            want.append(out)
+    L.audio_init()
+    try:
+        for b in blocks[:pool + 3]:
+            L.audio_fm_demodulator(np.ascontiguousarray(b).ctypes.data_as(C.c_void_p), n)
+        got = _drain(L, (pool + 3) * (n // 4))
+        assert got.size == pool * (n // 4)                       # three blocks were dropped
+        assert np.array_equal(got, np.concatenate(want[:pool]))
+        L.audio_fm_demodulator(np.ascontiguousarray(blocks[pool + 3]).ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(_drain(L, n // 4), want[pool])
+        # a second audio_init without audio_close restarts the queue only: the carried
+        # state (function statics in the reference, :76-79) survives
+        L.audio_fm_demodulator(np.ascontiguousarray(blocks[0]).ctypes.data_as(C.c_void_p), n)
+        L.audio_init()
+        assert L.audio_new_audio_available() == 0
+        nxt = oracle.audio_block(blocks[0], st)                  # the queued-then-discarded block
+        nxt = oracle.audio_block(blocks[1], st)
+        L.audio_fm_demodulator(np.ascontiguousarray(blocks[1]).ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(_drain(L, n // 4), nxt)
+    finally:
+        L.audio_close()

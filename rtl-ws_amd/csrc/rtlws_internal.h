@@ -139,15 +139,10 @@ constexpr int fused_lds_f2(int n_fft)
 {
     return 16 * 18 * (n_fft / 256) + 2;     // transposition 2 is the larger of the two
 }
-// last-pass twiddle pairs parked in LDS between frames (experiment: -DRTLWS_TW3_LDS=1)
-#ifndef RTLWS_TW3_LDS
-#define RTLWS_TW3_LDS 0
-#endif
-constexpr bool fused_tw3_in_lds(int n_fft) { return RTLWS_TW3_LDS && n_fft == 4096; }
 // ... in bytes, by input kind: the CIC staging slices share the buffer and may be the larger need
 constexpr int fused_lds_bytes(int n_fft, int in_kind)
 {
-    const int tr = 8 * (fused_lds_f2(n_fft) + (fused_tw3_in_lds(n_fft) ? 16 * (n_fft / 512) : 0));
+    const int tr = 8 * fused_lds_f2(n_fft);
     const int st = in_kind >= IN_CU8_CICR_LDS4 ? (n_fft / 1024) * cic_stage_wave_bytes(in_kind) : 0;
     return st > tr ? st : tr;
 }

@@ -65,6 +65,7 @@ static unsigned char* make_signal(size_t* nbytes, size_t buflen)
         fseek(f, 0, SEEK_SET);
         if (sz < 2) { fclose(f); return NULL; }
         data = (unsigned char*)malloc((size_t)sz);
+        if (!data) { fclose(f); return NULL; }
         if (fread(data, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(data); return NULL; }
         fclose(f);
         *nbytes = (size_t)sz - ((size_t)sz & 1u);
@@ -74,6 +75,7 @@ static unsigned char* make_signal(size_t* nbytes, size_t buflen)
         size_t n = buflen / 2, i;
         uint32_t x = 2463534242u;
         data = (unsigned char*)malloc(buflen);
+        if (!data) return NULL;
         for (i = 0; i < n; i++) {
             double ph = 2.0 * 3.14159265358979323846 * 0.125 * (double)i;
             double nr, ni;
@@ -106,6 +108,7 @@ int rtl_read_async(struct rtl_dev* dev, void (*callback)(unsigned char*, uint32_
     data = make_signal(&nbytes, buflen);
     if (!data) return -1;
     buf = (unsigned char*)malloc(buflen);
+    if (!buf) { free(data); return -1; }
     clock_gettime(CLOCK_MONOTONIC, &next);
 
     while (!dev->cancel) {

@@ -51,6 +51,13 @@ WORKLOADS = {
     "cic8_2048pt": (2048, 1, "rect", "power_sum", 8, 8192),
     # the reference's own factor at BASELINE's 2.4 MS/s (src/main.c:23,154: 2.4e6 / 192e3 = 12)
     "cic12_2048pt": (2048, 1, "rect", "power_sum", 12, 5456),
+    # the reference's default rate, 2.048 MS/s (src/rtl_sensor.c:12): 2.048e6 / 192e3 = 10
+    "cic10_2048pt": (2048, 1, "rect", "power_sum", 10, 6552),
+    # the other fused sizes of the batch API, reference behaviour (rectangular, K = 1)
+    "rect_2048pt": (2048, 1, "rect", "power_sum", 0, 32768),
+    "rect_4096pt": (4096, 1, "rect", "power_sum", 0, 16384),
+    # the product's own averaging (src/cbb_main.c:18: 6 frames per estimate), byte payload out
+    "k6_1024pt_payload": (1024, 6, "rect", "payload_u8", 0, 65536 - 65536 % 6),
     # stand-alone CIC (reference src/resample.c:6-45): "frame" = 2048 decimated outputs,
     # 2*8*2048 bytes in, 8*2048 bytes out; unit reported: decimated samples/s
     "cic8_block_sums": (2048, 1, "rect", "cs32", 8, 8192),
@@ -64,7 +71,8 @@ EXTRA_STEPS = 200
 def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum"):
     if output == "cs32":                       # stand-alone CIC: cmplx_s32 out
         return 2 * n_fft * cic_r + 8 * n_fft
-    return 2 * n_fft * max(cic_r, 1) + 4 * n_fft // k_avg
+    out_bytes = 1 if output == "payload_u8" else 4
+    return 2 * n_fft * max(cic_r, 1) + out_bytes * n_fft // k_avg
 
 
 def synth_iq_torch(torch, nframes, samples_per_frame, seed, device):
@@ -186,6 +194,11 @@ def parity_block(np, po, wl, host_in, got, nchk):
     if output == "mean_db":
         ref = 10 * np.log10(ref / k_avg)
         return {"frames": nchk, "max_abs_db_err": float(np.abs(got - ref).max())}
+    if output == "payload_u8":
+        want = np.stack([po.spectrum_payload(r, k_avg, 0) for r in ref])
+        diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        return {"frames": nchk, "bytes": int(want.size), "bytes_differing": int((diff != 0).sum()),
+                "max_byte_diff": int(diff.max())}
     mx = ref.max(axis=1, keepdims=True)
     strict = np.abs(got - ref) / np.maximum(ref, 1e-9 * mx)
     return {"frames": nchk,
@@ -212,7 +225,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
 
     # device-resident inputs / outputs, allocated by torch (plumbing only)
     ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(sets)]
-    out_dtype = torch.int32 if cic_only else torch.float32
+    out_dtype = torch.int32 if cic_only else (torch.uint8 if output == "payload_u8" else torch.float32)
     out_cols = 2 * n_fft if cic_only else n_fft
     outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
     stream = torch.cuda.current_stream().cuda_stream
@@ -279,7 +292,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32" if cic_only else "f32",
+            "dtype": "int32" if cic_only else "f32",      # arithmetic type of the path
             "data": "synthetic",
             "config": {"workload": name, "n_fft": n_fft, "frames_per_step": frames,
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,

@@ -96,9 +96,9 @@ struct SpectraParamsF64 {
 //   N = 1024: the rectangular K = 1 kernels (118-121 VGPRs) and every
 //     rectangular kind without prefetch registers or accumulators fit 4; a
 //     window (16 more registers) or K > 1 on the two prefetching kinds needs 3.
-//   N = 2048: the CIC-fused rectangular kinds fit 4 and are latency-bound on
-//     their loads, so they want every wave they can get; the rest carry R3 = 8
-//     last-pass twiddles and are built for 3.
+//   N = 2048: the rectangular K = 1 u8 kernel and the CIC-fused rectangular kinds fit
+//     4 and are faster there; the rest carry R3 = 8 last-pass twiddles plus a window
+//     or accumulators and are built for 3.
 //   N = 4096: 3 (R3 = 16 twiddles and a bigger last pass).
 // RTLWS_WAVES_BIG overrides the "3" for experiments.
 #ifndef RTLWS_WAVES_BIG
@@ -117,6 +117,9 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
     // (one instantiation family wants 171 VGPRs and the allocator spills 18 of them
     // at the 168 cap instead of finding the 3 it is short of: built for 2)
     if (n_fft == 2048 && in_kind == IN_CU8_CIC10 && win && !kone) return 2;
+    // the rectangular K = 1 2048-point u8 kernel fits 128 VGPRs (122) and is 7 % faster
+    // at 4 wavefronts per SIMD (0.59 against 0.55 of the HBM roofline, same call)
+    if (n_fft == 2048 && in_kind == IN_CU8 && !win && kone) return 4;
     const int by_regs = (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
                         : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
                         : RTLWS_WAVES_BIG;

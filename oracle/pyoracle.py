@@ -124,23 +124,29 @@ def spectrum_add_real_f32(N, src, ps, window=None, length=None):
                                            N if length is None else length)
 
 
-def batch_spectra_u8(src, N, K=1, window=None, nthreads=1):
-    """src: uint8 [nframes*N*2] (any shape); returns f64 [nframes/K, N]."""
+def batch_spectra_u8(src, N, K=1, window=None, nthreads=1, out=None):
+    """src: uint8 [nframes*N*2] (any shape); returns f64 [nframes/K, N].
+    out: optional preallocated result (timing loops reuse it: a fresh 128 MiB
+    array per call is page-faulted in, which costs more than the transforms)."""
     src = np.ascontiguousarray(src, dtype=np.uint8).reshape(-1)
     nframes = src.size // (2 * N)
     assert nframes * 2 * N == src.size and nframes % K == 0
-    out = np.empty((nframes // K, N), dtype=np.float64)
+    if out is None:
+        out = np.empty((nframes // K, N), dtype=np.float64)
+    assert out.shape == (nframes // K, N) and out.dtype == np.float64 and out.flags.c_contiguous
     w = _win(window, N)
     rc = lib().orc_batch_spectra_u8(N, K, nframes, _p(src), _p(w), _p(out), nthreads)
     assert rc == 0
     return out
 
 
-def batch_spectra_cic_u8(src, N, R, K=1, window=None, nthreads=1):
+def batch_spectra_cic_u8(src, N, R, K=1, window=None, nthreads=1, out=None):
     src = np.ascontiguousarray(src, dtype=np.uint8).reshape(-1)
     nframes = src.size // (2 * N * R)
     assert nframes * 2 * N * R == src.size and nframes % K == 0
-    out = np.empty((nframes // K, N), dtype=np.float64)
+    if out is None:
+        out = np.empty((nframes // K, N), dtype=np.float64)
+    assert out.shape == (nframes // K, N) and out.dtype == np.float64 and out.flags.c_contiguous
     w = _win(window, N)
     rc = lib().orc_batch_spectra_cic_u8(N, K, R, nframes, _p(src), _p(w), _p(out), nthreads)
     assert rc == 0

@@ -320,7 +320,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
 
 def cpu_baseline_block(np, po, wl, dev_in, frames):
     """The f64 oracle on this host's cores over a bounded sample of buffer set 0:
-    one thread, then every core of the job's CPU share, ~3 s each."""
+    one thread for 3 s, then every core of the job's CPU share for 1.5 s
+     -- about 27 CPU-seconds in all."""
     n_fft, k_avg, window, output, cic_r, _ = wl
     nproc = os.cpu_count()
     # the GPU box gives one GPU's job a 16-CPU share whatever nproc says
@@ -329,7 +330,7 @@ def cpu_baseline_block(np, po, wl, dev_in, frames):
     sample -= sample % k_avg
     host = dev_in[:sample].cpu().numpy()
 
-    def timed(nthreads, nframes, budget_s=3.0, max_reps=40):
+    def timed(nthreads, nframes, budget_s, max_reps=100000):
         h = host[:nframes]
         out = np.zeros((nframes // k_avg, n_fft), dtype=np.float64)    # touched once, reused
         reps, t_cpu = 0, 0.0
@@ -359,8 +360,8 @@ def cpu_baseline_block(np, po, wl, dev_in, frames):
                           % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
                              if po.ref_available() else "oracle/rtlws_oracle.c")}
     one_n = max(k_avg, (sample // 8) - (sample // 8) % k_avg)
-    v1, reps1 = timed(1, one_n)
-    vall, repsall = timed(cores, sample)
+    v1, reps1 = timed(1, one_n, 3.0)             # 3 CPU-seconds
+    vall, repsall = timed(cores, sample, 1.5)    # 1.5 s on every core: <= 24 CPU-seconds
     return {"value": vall, "unit": "spectra/s", "cores": cores, "kind": "port", "nproc": nproc,
             "one_thread": {"value": v1, "unit": "spectra/s", "cores": 1,
                            "sample": "%d frames of buffer set 0, %d repetitions" % (one_n, reps1)},

@@ -120,6 +120,8 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
     // the rectangular K = 1 2048-point u8 kernel fits 128 VGPRs (122) and is 7 % faster
     // at 4 wavefronts per SIMD (0.59 against 0.55 of the HBM roofline, same call)
     if (n_fft == 2048 && in_kind == IN_CU8 && !win && kone) return 4;
+    // (the rectangular cmplx_s32 / real-f32 input kinds of spectrum.h fit as well: 127 / 124)
+    if (n_fft == 2048 && (in_kind == IN_CS32 || in_kind == IN_RF32) && !win) return 4;
     const int by_regs = (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
                         : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
                         : RTLWS_WAVES_BIG;

@@ -116,9 +116,9 @@ def test_cic_fused_every_input_stage(engine, oracle, N, R):
     assert rel_err(engine.spectra(iq, N, cic_r=R, k_avg=3), ref3, EPS_K1).max() <= TOL
 
 
-def test_s32_and_f32_inputs(engine, oracle):
-    rng = np.random.default_rng(8)
-    N = 1024
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+def test_s32_and_f32_inputs(engine, oracle, N):
+    rng = np.random.default_rng(8 + N)
     s32 = rng.integers(-1024, 1024, size=(4, N, 2), dtype=np.int32)
     got = engine.spectra(s32, N, input="cs32")
     for r in range(4):

@@ -114,9 +114,9 @@ constexpr int fused_lds_bytes(int n_fft, int in_kind);
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
     const bool acc_and_prefetch = !kone && fused_kone_kind(in_kind);
-    // (one instantiation family wants 171 VGPRs and the allocator spills 18 of them
+    // (two instantiation families want ~171 VGPRs and the allocator spills 18 of them
     // at the 168 cap instead of finding the 3 it is short of: built for 2)
-    if (n_fft == 2048 && in_kind == IN_CU8_CIC10 && win && !kone) return 2;
+    if (n_fft == 2048 && in_kind >= IN_CU8_CIC10 && win && !kone) return 2;
     // the rectangular K = 1 2048-point u8 kernel fits 128 VGPRs (122) and is 7 % faster
     // at 4 wavefronts per SIMD (0.59 against 0.55 of the HBM roofline, same call)
     if (n_fft == 2048 && in_kind == IN_CU8 && !win && kone) return 4;

@@ -19,10 +19,19 @@
  *
  * Per sensor buffer the engine does what src/cbb_main.c:40-70 does: at most
  * every 250 ms, the first min(len/1024, 6) frames of the buffer become ONE
- * launch of the fused kernel (K = blocks); the 1024 f32 sums stay on the
- * device and the dB/clamp conversion is a second small kernel at payload time.
- * With RTLWS_CBB_ALL_FRAMES=1 in the environment at cbb_init, every whole frame
- * of the buffer is averaged instead of the first 6 (same payload format).
+ * launch of the f64 kernel (K = blocks; the reference keeps doubles,
+ * src/cbb_main.c:27); the 1024 double sums stay on the device and the dB/clamp
+ * conversion, in double, is a second small kernel at payload time.  The sensor
+ * thread never waits for the device.
+ *
+ * Extensions, chosen by RTLWS_CBB_ALL_FRAMES in the environment at cbb_init
+ * (same payload format, same calls):
+ *   1  every whole frame of the buffer that passes the 250 ms gate is averaged
+ *      (128 at librtlsdr's default buffer size) instead of its first 6;
+ *   2  Welch averaging over the whole interval: EVERY buffer is transformed, all
+ *      frames of it, and the gate only decides when the running average is
+ *      published -- no sample of the stream is thrown away.  The published row
+ *      is exactly what the reference's loop would leave after that many frames.
  */
 #ifndef CBB_MAIN_H
 #define CBB_MAIN_H

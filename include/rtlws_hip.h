@@ -158,6 +158,22 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* desc, con
 int rtlws_payload_from_sums_f64(rtlws_engine* e, const double* d_sums, int n, int count, int gain_db,
                                 void* d_out_u8, void* stream);
 
+/* Averaging over SEVERAL launches with the reference's semantics (cbb_main.h's
+ * RTLWS_CBB_ALL_FRAMES=2 mode: every sensor buffer of a 250 ms interval).  Each
+ * launch j of rtlws_spectra_batch_f64 (RTLWS_OUT_POWER_SUM, k_avg = K_j, one row)
+ * is folded into a running row with
+ *   rtlws_welch_accumulate_f64(e, d_acc, d_row_j, n, frames_end_j, d_b)
+ * where frames_end_j = K_0 + ... + K_j, and the interval is closed with
+ *   rtlws_welch_finish_f64(e, d_acc, n, total_frames, d_b)
+ * after which d_acc holds exactly what total_frames sequential spectrum_add_*
+ * calls leave in a zeroed buffer -- including slot n/2, whose weights
+ * (src/spectrum.c:25-33) depend on the position of a frame in the whole sequence --
+ * and *d_b is zero again.  d_acc (n doubles) and d_b (one double) start zeroed.
+ * 0 / -1 / -3. */
+int rtlws_welch_accumulate_f64(rtlws_engine* e, double* d_acc, const double* d_part, int n,
+                               long frames_end, double* d_b, void* stream);
+int rtlws_welch_finish_f64(rtlws_engine* e, double* d_acc, int n, long total, double* d_b, void* stream);
+
 /* Which kernel a descriptor selects: 1 fused, 2 direct DFT, 0 unsupported. */
 int rtlws_spectra_kernel_kind(const rtlws_spectra_desc* desc);
 

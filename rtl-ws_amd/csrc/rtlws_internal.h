@@ -163,6 +163,8 @@ hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, f
                            float* d_out, hipStream_t);
 hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t);
 hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t);
+hipError_t launch_welch_accumulate(double* d_acc, const double* d_part, int n, long frames_end, double* d_b, hipStream_t);
+hipError_t launch_welch_finish(double* d_acc, int n, long total, double* d_b, hipStream_t);
 hipError_t launch_payload_f64(const double* d_sums, int n, double gain, int count, uint8_t* d_out, hipStream_t);
 
 }  // namespace rtlws

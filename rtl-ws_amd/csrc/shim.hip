@@ -628,6 +628,33 @@ int rtlws_payload_from_sums_f64(rtlws_engine* e, const double* d_sums, int n, in
     return 0;
 }
 
+int rtlws_welch_accumulate_f64(rtlws_engine* e, double* d_acc, const double* d_part, int n,
+                               long frames_end, double* d_b, void* stream)
+{
+    g_err.clear();
+    if (!e || n < 2 || frames_end < 0 || !d_acc || !d_part || !d_b) {
+        g_err = "rtlws_welch_accumulate_f64: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_welch_accumulate(d_acc, d_part, n, frames_end, d_b, pick_stream(e, stream));
+    if (err != hipSuccess) { set_err("welch accumulate kernel launch", err); return -3; }
+    return 0;
+}
+
+int rtlws_welch_finish_f64(rtlws_engine* e, double* d_acc, int n, long total, double* d_b, void* stream)
+{
+    g_err.clear();
+    if (!e || n < 2 || total < 0 || !d_acc || !d_b) {
+        g_err = "rtlws_welch_finish_f64: bad argument";
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    hipError_t err = rtlws::launch_welch_finish(d_acc, n, total, d_b, pick_stream(e, stream));
+    if (err != hipSuccess) { set_err("welch finish kernel launch", err); return -3; }
+    return 0;
+}
+
 int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len, void* d_dst,
                          void* stream)
 {

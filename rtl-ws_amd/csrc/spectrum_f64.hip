@@ -164,6 +164,47 @@ hipError_t launch_payload_f64(const double* d_sums, int n, double gain, int coun
     return hipGetLastError();
 }
 
+// Welch accumulation across launches (cbb_main.h, RTLWS_CBB_ALL_FRAMES=2): every
+// sensor buffer of a 250 ms interval contributes one row of K_j-frame sums; the
+// published row must be what the reference's sequential loop (src/spectrum.c:25-33,
+// src/cbb_main.c:50-59) would leave after ALL those frames in one zeroed buffer.
+// Every slot but N/2 is a plain sum.  Slot N/2 is sum_k (Ktot - k) P_k[N-1]; with
+// launch j covering frames s_j .. s_j+K_j-1 its own output there is
+// dc_j = sum_i (K_j - i) P, so the total is
+//   sum_j dc_j + Ktot * sum_j S_j - sum_j (s_j + K_j) S_j,   S_j = row_j[N/2 - 1],
+// i.e. the accumulated slot plus Ktot times the accumulated neighbour minus a
+// scalar B that is carried beside the row.
+__global__ __launch_bounds__(256) void welch_accumulate_kernel(double* __restrict__ acc,
+                                                               const double* __restrict__ part, int n,
+                                                               double frames_end, double* __restrict__ b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += part[i];
+    if (i == 0) *b += part[n / 2 - 1] * frames_end;
+}
+
+__global__ void welch_finish_kernel(double* __restrict__ acc, int n, double total, double* __restrict__ b)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        acc[n / 2] += total * acc[n / 2 - 1] - *b;
+        *b = 0.0;
+    }
+}
+
+hipError_t launch_welch_accumulate(double* d_acc, const double* d_part, int n, long frames_end,
+                                   double* d_b, hipStream_t st)
+{
+    hipLaunchKernelGGL(welch_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_acc, d_part, n,
+                       (double)frames_end, d_b);
+    return hipGetLastError();
+}
+
+hipError_t launch_welch_finish(double* d_acc, int n, long total, double* d_b, hipStream_t st)
+{
+    hipLaunchKernelGGL(welch_finish_kernel, dim3(1), dim3(64), 0, st, d_acc, n, (double)total, d_b);
+    return hipGetLastError();
+}
+
 template <int IN>
 static hipError_t launch_f64_in(const SpectraParamsF64& p, hipStream_t st)
 {

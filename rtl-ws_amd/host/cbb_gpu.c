@@ -55,8 +55,16 @@ static int g_pub_count = 0;             /* frames behind g_d_pub */
 static uint64_t g_last_est_ms = 0;
 static volatile int g_new_spectrum = 0;
 static uint64_t g_samples_seen = 0;
-static int g_max_blocks = FFT_AVERAGE;  /* RTLWS_CBB_ALL_FRAMES=1: every frame of the buffer */
-#define MAX_BLOCKS_ALL 1024             /* device staging bound for that mode (2 MiB of IQ)  */
+static int g_max_blocks = FFT_AVERAGE;  /* RTLWS_CBB_ALL_FRAMES=1|2: every frame of the buffer */
+#define MAX_BLOCKS_ALL 1024             /* device staging bound for those modes (2 MiB of IQ) */
+/* RTLWS_CBB_ALL_FRAMES=2 ("Welch averaging over the whole 250 ms"):
+ * EVERY sensor buffer is transformed, all of its frames, and folded into a running
+ * row; the 250 ms gate only decides when that row is published.  The published
+ * spectrum is what the reference's loop would leave after all those frames. */
+static int g_welch = 0;
+static double* g_d_acc = NULL;          /* running row of the current interval            */
+static double* g_d_b = NULL;            /* scalar carried beside it (rtlws_welch_*_f64)   */
+static long g_acc_count = 0;            /* frames folded into g_d_acc so far              */
 
 static uint64_t now_ms(void)
 {
@@ -85,7 +93,8 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
     int blocks = len / FFT_POINTS;
     rtlws_spectra_desc d;
 
-    if (now_ms() < g_last_est_ms + SPECTRUM_EST_MS) return;      /* :46-47 */
+    const int due = now_ms() >= g_last_est_ms + SPECTRUM_EST_MS;  /* :46-47 */
+    if (!due && !g_welch) return;
     blocks = blocks <= g_max_blocks ? blocks : g_max_blocks;     /* :49 (6 unless ALL_FRAMES) */
 
     pthread_mutex_lock(&g_mu);
@@ -104,11 +113,38 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
         g_iq_used[slot] = 1;
         if (rtlws_copy_h2d(g_eng, g_d_iq, g_h_iq[slot], bytes, NULL) ||
             rtlws_event_record(g_iq_done[slot], g_eng, NULL) ||
-            rtlws_spectra_batch_f64(g_eng, &d, g_d_iq, blocks, g_d_work, NULL)) {
+            rtlws_spectra_batch_f64(g_eng, &d, g_d_iq, blocks, g_d_work, NULL) ||
+            (g_welch && rtlws_welch_accumulate_f64(g_eng, g_d_acc, g_d_work, FFT_POINTS,
+                                                   g_acc_count + blocks, g_d_b, NULL))) {
             fprintf(stderr, "rtlws: estimate_spectrum: device failure: %s\n", rtlws_last_error());
             pthread_mutex_unlock(&g_mu);
             return;                                               /* :54-58 */
         }
+        g_acc_count += blocks;
+    }
+    if (g_welch) {
+        if (!due) {                              /* folded in; the interval is still open */
+            pthread_mutex_unlock(&g_mu);
+            return;
+        }
+        /* close the interval: fix slot N/2 for the whole sequence, publish, start over */
+        if (rtlws_welch_finish_f64(g_eng, g_d_acc, FFT_POINTS, g_acc_count, g_d_b, NULL)) {
+            fprintf(stderr, "rtlws: estimate_spectrum: device failure: %s\n", rtlws_last_error());
+            pthread_mutex_unlock(&g_mu);
+            return;
+        }
+        {
+            double* t = g_d_pub;
+            g_d_pub = g_d_acc;
+            g_d_acc = t;
+            g_pub_count = (int)g_acc_count;
+            g_acc_count = 0;
+            rtlws_memset_dev(g_eng, g_d_acc, 0, FFT_POINTS * sizeof(double), NULL);
+        }
+        g_last_est_ms = now_ms();
+        g_new_spectrum = 1;
+        pthread_mutex_unlock(&g_mu);
+        return;
     }
     g_last_est_ms = now_ms();                                     /* :61 */
     g_new_spectrum = 1;                                           /* :62 */
@@ -139,11 +175,17 @@ void cbb_init(int decimated_bw_target_hz)
          * all of them (K = len/1024) -- same payload format, smoother spectrum */
         const char* all = getenv("RTLWS_CBB_ALL_FRAMES");
         g_max_blocks = (all && atoi(all) > 0) ? MAX_BLOCKS_ALL : FFT_AVERAGE;
+        g_welch = (all && atoi(all) == 2);
     }
     g_d_iq = rtlws_dev_alloc(g_eng, (size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
     g_d_work = (double*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(double));
     g_d_pub = (double*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(double));
     g_d_payload = rtlws_dev_alloc(g_eng, FFT_POINTS);
+    g_d_acc = (double*)rtlws_dev_alloc(g_eng, FFT_POINTS * sizeof(double));
+    g_d_b = (double*)rtlws_dev_alloc(g_eng, sizeof(double));
+    if (g_d_acc) rtlws_memset_dev(g_eng, g_d_acc, 0, FFT_POINTS * sizeof(double), NULL);
+    if (g_d_b) rtlws_memset_dev(g_eng, g_d_b, 0, sizeof(double), NULL);
+    g_acc_count = 0;
     {
         int k;
         for (k = 0; k < IQ_SLOTS; ++k) {
@@ -154,7 +196,7 @@ void cbb_init(int decimated_bw_target_hz)
         g_iq_next = 0;
     }
     g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
-    if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_h_iq[0] || !g_h_iq[1] ||
+    if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_d_acc || !g_d_b || !g_h_iq[0] || !g_h_iq[1] ||
         !g_iq_done[0] || !g_iq_done[1] || !g_h_payload) {
         fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
         abort();
@@ -208,6 +250,9 @@ void cbb_close(void)
         rtlws_dev_free(g_eng, g_d_work);
         rtlws_dev_free(g_eng, g_d_pub);
         rtlws_dev_free(g_eng, g_d_payload);
+        rtlws_dev_free(g_eng, g_d_acc);
+        rtlws_dev_free(g_eng, g_d_b);
+        g_d_acc = g_d_b = NULL;
         {
             int k;
             rtlws_stream_sync(g_eng, NULL);
@@ -226,6 +271,16 @@ void cbb_close(void)
     pthread_mutex_unlock(&g_mu);
     rtl_close(g_dev);                                             /* :149 */
     g_dev = NULL;
+}
+
+/* test/diagnostic hook: frames behind the spectrum the next payload call will convert */
+int rtlws_cbb_published_frames(void)
+{
+    int n;
+    pthread_mutex_lock(&g_mu);
+    n = g_pub_count;
+    pthread_mutex_unlock(&g_mu);
+    return n;
 }
 
 /* test/diagnostic hook: complex samples the callbacks have seen so far */

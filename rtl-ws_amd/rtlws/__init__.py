@@ -65,6 +65,7 @@ HIP_SYMBOLS = [
     "rtlws_event_elapsed_ms", "rtlws_event_sync", "rtlws_spectra_batch", "rtlws_spectra_kernel_kind",
     "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
     "rtlws_fm_demod", "rtlws_copy_d2d", "rtlws_spectra_batch_f64", "rtlws_payload_from_sums_f64",
+    "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
@@ -138,6 +139,8 @@ def hip_lib():
         L.rtlws_spectra_batch.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
         L.rtlws_spectra_batch_f64.argtypes = [vp, C.POINTER(SpectraDesc), vp, l, vp, vp]
         L.rtlws_payload_from_sums_f64.argtypes = [vp, vp, i, i, i, vp, vp]
+        L.rtlws_welch_accumulate_f64.argtypes = [vp, vp, vp, i, l, vp, vp]
+        L.rtlws_welch_finish_f64.argtypes = [vp, vp, i, l, vp, vp]
         L.rtlws_spectra_kernel_kind.argtypes = [C.POINTER(SpectraDesc)]
         L.rtlws_cic_block_sums.argtypes = [vp, i, vp, l, vp, vp]
         L.rtlws_halfband.argtypes = [vp, vp, vp, l, vp]

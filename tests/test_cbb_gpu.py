@@ -175,3 +175,52 @@ def test_all_frames_mode(tmp_path, built, oracle):
     want = oracle.spectrum_payload(ref, 128, 0)
     for (got,) in payloads:
         assert got.size == 1024 and np.array_equal(got, want)
+
+
+def test_welch_mode_every_buffer_of_the_interval(tmp_path, built, oracle):
+    """RTLWS_CBB_ALL_FRAMES=2: every sensor buffer is transformed (all 128 frames of it)
+    and the 250 ms gate only publishes the running average.  The replayed recording is one
+    buffer, so an interval of m buffers is the same 128 frames m times over, and the
+    published row must be what the reference's sequential loop leaves after 128*m frames
+    -- slot N/2 included, whose weights depend on a frame's position in the WHOLE sequence
+    (rtlws_welch_accumulate_f64 / rtlws_welch_finish_f64)."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(1, BUF_SAMPLES, seed=12).reshape(-1, 2)
+    rec = tmp_path / "iq.u8"
+    iq.tofile(rec)
+    os.environ["RTLWS_SYNTH_FILE"] = str(rec)
+    os.environ["RTLWS_SYNTH_SPEEDUP"] = "1.0"
+    os.environ["RTLWS_SYNTH_BUFLEN"] = str(2 * BUF_SAMPLES)
+    os.environ.pop("RTLWS_SYNTH_MAXBUFS", None)
+    os.environ["RTLWS_CBB_ALL_FRAMES"] = "2"
+    L = built.cbb_lib()
+    L.rtlws_cbb_published_frames.restype = __import__("ctypes").c_int
+    got = []
+    try:
+        L.cbb_init(192000)
+        import ctypes as C
+        synth_lib = C.CDLL(built.SYNTH_LIB, mode=C.RTLD_GLOBAL)
+        synth_lib.rtl_set_sample_rate.argtypes = [C.c_void_p, C.c_uint32]
+        synth_lib.rtl_set_sample_rate(L.cbb_get_rtl_dev(), 2400000)
+        t0 = time.time()
+        while time.time() - t0 < 1.6:
+            if L.cbb_new_spectrum_available():
+                frames = L.rtlws_cbb_published_frames()
+                got.append((frames, built.cbb_payload(0), built.cbb_payload(15)))
+            time.sleep(0.002)
+    finally:
+        L.cbb_close()
+        os.environ.pop("RTLWS_CBB_ALL_FRAMES", None)
+    assert len(got) >= 3
+    # 2.4 MS/s, 54.6 ms buffers, 250 ms gate: 4-5 buffers = 512-640 frames per interval
+    # (the first interval may be shorter or longer: cold start)
+    assert all(f % 128 == 0 and f >= 128 for f, _, _ in got)
+    assert any(f >= 512 for f, _, _ in got)
+    cache = {}
+    for frames, p0, p15 in got:
+        if frames not in cache:
+            m = frames // 128
+            cache[frames] = oracle.batch_spectra_u8(np.tile(iq, (m, 1)), 1024, K=frames, nthreads=8)[0]
+        ref = cache[frames]
+        assert np.array_equal(p0, oracle.spectrum_payload(ref, frames, 0))
+        assert np.array_equal(p15, oracle.spectrum_payload(ref, frames, 15))

@@ -305,3 +305,30 @@ def test_cic_reference_factors_windowed_and_averaged(engine, oracle, N, R):
     ref = oracle.batch_spectra_cic_u8(iq, N, R, K=4)
     db = engine.spectra(iq, N, cic_r=R, k_avg=4, output="mean_db")
     assert np.abs(db - 10 * np.log10(ref / 4)).max() <= 2e-4
+
+
+def test_welch_accumulation_matches_one_long_average(engine, oracle, built):
+    """rtlws_welch_accumulate_f64 / rtlws_welch_finish_f64: rows of K_j-frame sums from
+    several launches folded into one row equal ONE launch over all the frames -- slot N/2
+    included (its weight for a frame is Ktot minus the frame's position in the whole
+    sequence, src/spectrum.c:25-33)."""
+    from rtlws import synth
+    L = built.hip_lib()
+    N = 1024
+    parts = [3, 1, 6, 2]
+    iq = synth.tone_noise_iq(sum(parts), N, seed=77)
+    d_acc = engine.upload(np.zeros(N))
+    d_b = engine.upload(np.zeros(1))
+    done = 0
+    for K in parts:
+        row = engine.spectra(iq[done:done + K], N, k_avg=K, f64=True)
+        d_row = engine.upload(row)
+        done += K
+        assert L.rtlws_welch_accumulate_f64(engine.h, d_acc.ptr, d_row.ptr, N, done, d_b.ptr, None) == 0
+    assert L.rtlws_welch_finish_f64(engine.h, d_acc.ptr, N, done, d_b.ptr, None) == 0
+    got = engine.download(d_acc, np.float64, (N,))
+    assert engine.download(d_b, np.float64, (1,))[0] == 0.0
+    ref = oracle.batch_spectra_u8(iq, N, K=done)[0]
+    assert rel_err(got, ref, EPS_STRICT).max() <= TOL_F64
+    assert abs(got[N // 2] - ref[N // 2]) <= 1e-12 * ref[N // 2]
+    assert L.rtlws_welch_accumulate_f64(engine.h, d_acc.ptr, d_acc.ptr, 1, 1, d_b.ptr, None) == -1

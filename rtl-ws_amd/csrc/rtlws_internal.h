@@ -93,9 +93,11 @@ struct SpectraParamsF64 {
 // second argument), by instantiation, chosen so that NO instantiation spills
 // (tests/test_abi_cpu.py reads the code-object metadata and fails on any
 // vgpr_spill_count > 0).  4 waves/SIMD = 128 VGPRs, 3 = 168.
-//   N = 1024: the rectangular K = 1 kernels (118-121 VGPRs) and every
+//   N = 1024: the rectangular K = 1 kernels (117-121 VGPRs) and every
 //     rectangular kind without prefetch registers or accumulators fit 4; a
 //     window (16 more registers) or K > 1 on the two prefetching kinds needs 3.
+//     The headline kernel is LAUNCHED at 2 (below): an occupancy choice, not a
+//     register limit.
 //   N = 2048: the rectangular K = 1 u8 kernel and the CIC-fused rectangular kinds fit
 //     4 and are faster there; the rest carry R3 = 8 last-pass twiddles plus a window
 //     or accumulators and are built for 3.
@@ -122,6 +124,13 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
     if (n_fft == 2048 && in_kind == IN_CU8 && !win && kone) return 4;
     // (the rectangular cmplx_s32 / real-f32 input kinds of spectrum.h fit as well: 127 / 124)
     if (n_fft == 2048 && (in_kind == IN_CS32 || in_kind == IN_RF32) && !win) return 4;
+    // The headline kernel (1024-point, u8, rectangular, K = 1; 117 VGPRs) runs 8 one-wave
+    // workgroups per CU, 2 per SIMD, 32 rows each at 65 536 rows: measured 0.66-0.67
+    // against 0.63-0.65 for 16 on one box, +1 % on two others, never slower, and steadier
+    // from run to run (12, 10 and 7 per CU are in between, 9 -- uneven over the four
+    // SIMDs -- and 6 or fewer are slower).  The kernel is at the package power cap
+    // either way; fewer resident wavefronts queue less on the LDS pipe.
+    if (n_fft == 1024 && in_kind == IN_CU8 && !win && kone) return 2;
     const int by_regs = (n_fft == 1024 && !win && !acc_and_prefetch) ? 4
                         : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
                         : RTLWS_WAVES_BIG;

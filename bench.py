@@ -318,7 +318,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     return result
 
 
-def cpu_baseline_block(np, po, wl, dev_in, frames):
+def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
     """The f64 oracle on this host's cores over a bounded sample of buffer set 0:
     one thread for 3 s, then every core of the job's CPU share for 1.5 s
      -- about 27 CPU-seconds in all."""
@@ -346,7 +346,7 @@ def cpu_baseline_block(np, po, wl, dev_in, frames):
 
     if output == "cs32":                       # one thread: the loop carries a dependency
         reps, t_cpu = 0, 0.0
-        while t_cpu < 3.0 and reps < 20:
+        while t_cpu < 3.0 * budget_scale and reps < 20:
             c0 = time.perf_counter()
             if po.ref_available():             # the reference's own object code (oracle/_ref)
                 po.ref_cic_decimate(cic_r, host.reshape(-1, 2))
@@ -360,8 +360,8 @@ def cpu_baseline_block(np, po, wl, dev_in, frames):
                           % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
                              if po.ref_available() else "oracle/rtlws_oracle.c")}
     one_n = max(k_avg, (sample // 8) - (sample // 8) % k_avg)
-    v1, reps1 = timed(1, one_n, 3.0)             # 3 CPU-seconds
-    vall, repsall = timed(cores, sample, 1.5)    # 1.5 s on every core: <= 24 CPU-seconds
+    v1, reps1 = timed(1, one_n, 3.0 * budget_scale)             # 3 CPU-seconds
+    vall, repsall = timed(cores, sample, 1.5 * budget_scale)    # 1.5 s on every core: <= 24 CPU-seconds
     return {"value": vall, "unit": "spectra/s", "cores": cores, "kind": "port", "nproc": nproc,
             "one_thread": {"value": v1, "unit": "spectra/s", "cores": 1,
                            "sample": "%d frames of buffer set 0, %d repetitions" % (one_n, reps1)},

@@ -61,17 +61,21 @@ WORKLOADS = {
     # stand-alone CIC (reference src/resample.c:6-45): "frame" = 2048 decimated outputs,
     # 2*8*2048 bytes in, 8*2048 bytes out; unit reported: decimated samples/s
     "cic8_block_sums": (2048, 1, "rect", "cs32", 8, 8192),
+    # the reference's own precision on batches (src/spectrum.c:54-60,28 is f64 end to end):
+    # rtlws_spectra_batch_f64, rows of doubles out -- 2N + 8N/K = 10 240 B per spectrum
+    "batched_1024pt_64k_frames_f64": (1024, 1, "rect", "power_sum", 0, 65536),
 }
+F64_WORKLOADS = ("batched_1024pt_64k_frames_f64",)
 HEADLINE = "batched_1024pt_64k_frames"
 # configs[2], configs[3] and the reference's own decimation factor ride along on the default line
 EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt")
 EXTRA_STEPS = 200
 
 
-def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum"):
+def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum", f64=False):
     if output == "cs32":                       # stand-alone CIC: cmplx_s32 out
         return 2 * n_fft * cic_r + 8 * n_fft
-    out_bytes = 1 if output == "payload_u8" else 4
+    out_bytes = 1 if output == "payload_u8" else (8 if f64 else 4)   # f64 rows are 8N/K
     return 2 * n_fft * max(cic_r, 1) + out_bytes * n_fft // k_avg
 
 
@@ -200,6 +204,17 @@ def parity_block(np, po, wl, host_in, got, nchk):
         return {"frames": nchk, "bytes": int(want.size), "bytes_differing": int((diff != 0).sum()),
                 "max_byte_diff": int(diff.max())}
     mx = ref.max(axis=1, keepdims=True)
+    # An all-zero oracle row means a CONSTANT input frame (only the DC bin is excited and it
+    # is never output, src/spectrum.c:31): the seeded tone + noise never produces one, so
+    # the input the kernel consumed is not the input that was synthesised.  Say which rows,
+    # and let the caller fail instead of printing 0/0.
+    dead = np.nonzero(mx[:, 0] <= 0)[0]
+    if dead.size:
+        rows_in = host_in.reshape(ref.shape[0], -1)
+        return {"frames": nchk, "non_finite": True,
+                "constant_input_rows": [int(r) for r in dead[:16]], "constant_input_row_count": int(dead.size),
+                "input_byte_min_max_of_those_rows": [[int(rows_in[r].min()), int(rows_in[r].max())] for r in dead[:16]],
+                "kernel_output_max_of_those_rows": [float(got[r].max()) for r in dead[:16]]}
     strict = np.abs(got - ref) / np.maximum(ref, 1e-9 * mx)
     return {"frames": nchk,
             "max_rel_err_floor1e-5": float((np.abs(got - ref) / np.maximum(ref, 1e-5 * mx)).max()),
@@ -207,15 +222,59 @@ def parity_block(np, po, wl, host_in, got, nchk):
             "p99.9_rel_err_floor1e-9": float(np.percentile(strict, 99.9))}
 
 
+# what a parity block must hold for the line to be printed with exit code 0 (the f32 batch
+# kernel's budget, DESIGN.md §5: the same bounds tests/ assert)
+PARITY_BOUNDS = {"max_rel_err_floor1e-5": 1e-4, "max_rel_err_floor1e-9": 5e-3, "p99.9_rel_err_floor1e-9": 1e-4,
+                 "max_abs_db_err": 2e-4, "max_byte_diff": 1}
+PARITY_BOUNDS_F64 = {"max_rel_err_floor1e-9": 1e-10}
+
+
+def parity_failures(block, bounds=None):
+    """Names of the statistics of a parity block that are non-finite or over their bound."""
+    import math
+    bounds = PARITY_BOUNDS if bounds is None else bounds
+    bad = []
+    if block.get("non_finite"):
+        bad.append("constant_input_rows")
+    if block.get("bit_exact") is False:
+        bad.append("bit_exact")
+    for k, v in block.items():
+        if isinstance(v, float) and not math.isfinite(v):
+            bad.append(k)
+        elif k in bounds and isinstance(v, (int, float)) and v > bounds[k]:
+            bad.append(k)
+    return bad
+
+
+def gather_ranks(torch, dist, value, device=None):
+    """The value of every rank, in rank order ([value] when dist is None)."""
+    if dist is None:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x[0]) for x in out]
+
+
 def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False):
     """Allocate `sets` rotating buffer sets, run max(warmup, SETTLE_LAUNCHES)
     untimed launches, time exactly `steps` launches between barrier +
     synchronise on both sides (wall clock -> value) and between HIP events on
-    the launch stream (-> roofline), MAX over ranks.  Returns rank 0's dict."""
+    the launch stream (-> roofline), MAX over ranks.  Returns rank 0's dict.
+
+    Stream order: inputs are synthesised, and every launch is enqueued, on ONE
+    side stream of torch's (ctx["stream"]): its handle is non-zero, so the
+    engine launches on exactly that stream (a zero handle -- torch's default
+    stream -- would select the engine's own non-blocking stream, which is not
+    ordered against torch's kernels: include/rtlws_hip.h "Streams").  The
+    outputs are allocated before the synthesis temporaries exist and the
+    device is synchronised before the first launch, so no launch can write
+    into memory a synthesis kernel still reads."""
     torch, np, rtlws, eng = ctx["torch"], ctx["np"], ctx["rtlws"], ctx["eng"]
     dist, world, rank, device = ctx["dist"], ctx["world"], ctx["rank"], ctx["device"]
     wl = WORKLOADS[name]
     n_fft, k_avg, window, output, cic_r, frames = wl
+    f64 = name in F64_WORKLOADS
     if frames_override > 0:
         frames = frames_override - frames_override % k_avg
     spf = n_fft * max(cic_r, 1)
@@ -224,19 +283,25 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     rows = frames // k_avg
 
     # device-resident inputs / outputs, allocated by torch (plumbing only)
-    ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(sets)]
-    out_dtype = torch.int32 if cic_only else (torch.uint8 if output == "payload_u8" else torch.float32)
+    tstream = ctx["stream"]
+    stream = tstream.cuda_stream
+    assert stream != 0, "bench.py launches on a side stream; a zero handle would select the engine's own"
+    out_dtype = torch.int32 if cic_only else (torch.uint8 if output == "payload_u8" else
+                                              (torch.float64 if f64 else torch.float32))
     out_cols = 2 * n_fft if cic_only else n_fft
-    outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
-    stream = torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(tstream):
+        outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
+        ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(sets)]
+    torch.cuda.synchronize()
     L = rtlws.hip_lib()
+    launch = eng.spectra_batch_f64 if f64 else eng.spectra_batch
 
     def step(i):
         s = i % sets
         if cic_only:
             eng.cic_block_sums(cic_r, ins[s].data_ptr(), frames * n_fft, outs[s].data_ptr(), stream=stream)
         else:
-            eng.spectra_batch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
+            launch(desc, ins[s].data_ptr(), frames, outs[s].data_ptr(), stream=stream)
 
     # The kernels run at the package power cap and the clock governor needs
     # ~300 launches (25 ms) to settle: whatever W is, at least
@@ -256,27 +321,35 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         step(i)
     L.rtlws_event_record(ev1, eng.h, stream)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0        # this rank's launches, before waiting for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
-    elapsed, ev_ms = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
+    elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
+    per_rank_own = gather_ranks(torch, dist, 1e3 * own_elapsed / steps, device)
+    per_rank_ev = gather_ranks(torch, dist, ev_ms / steps, device)
+    ev_ms = ev_ms_max
 
     result = None
     if rank == 0:
         value = whole_job_rate(world, steps, frames, elapsed)
-        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output) * frames
+        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, f64) * frames
         avg_launch_s = (ev_ms / 1e3) / steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
+        achieved_wall = bytes_per_launch / (elapsed / steps) / 1e9
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(name, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
+            if traffic is not None:
+                traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "workload, committed; NOT measured by this run")
         if cic_only:
             value *= n_fft                      # decimated samples per second
         result = {
@@ -292,17 +365,35 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32" if cic_only else "f32",      # arithmetic type of the path
+            "dtype": "int32" if cic_only else ("f64" if f64 else "f32"),      # arithmetic type of the path
             "data": "synthetic",
             "config": {"workload": name, "n_fft": n_fft, "frames_per_step": frames,
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
                        "input": "cmplx_u8 tone(0.6)+noise(0.05), device-resident, %d rotating sets" % sets,
                        "sharding": "independent frames per GPU, no collective"},
+            # frac      : algorithmic bytes / average launch duration between HIP events recorded on the
+            #             launch stream around the timed launches (the kernel's own time)
+            # frac_wall : the same bytes / ms_per_step, the host wall clock `value` is computed from
+            #             (barrier + synchronise on both sides; includes the sync and launch overheads)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_clock": "hip_events_on_launch_stream",
+                         "achieved_wall": achieved_wall, "frac_wall": achieved_wall / HBM_PEAK_GBS,
+                         "frac_wall_clock": "host_perf_counter_ms_per_step",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": 1e6 * avg_launch_s},
         }
+        vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256))
+        if vf is not None:
+            result["roofline"].update(vf)
+        if world > 1:
+            # every rank's own figures, so a scaling loss is visible in this one line
+            result["per_rank"] = {"ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
+                                                      "all": per_rank_own},
+                                  "event_ms_per_step": {"min": min(per_rank_ev), "max": max(per_rank_ev),
+                                                        "all": per_rank_ev},
+                                  "note": "own = each rank's wall clock around its launches + synchronise, before "
+                                          "the closing barrier; ms_per_step is the MAX over ranks incl. the barrier"}
 
         # parity spot check of what was just timed (first 256 rows of set 0)
         from oracle import pyoracle as po
@@ -310,6 +401,9 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         host_in = ins[0][:nchk].cpu().numpy()
         got = outs[0][:nchk if cic_only else 256].cpu().numpy()
         result["parity"] = parity_block(np, po, wl, host_in, got, nchk)
+        bad = parity_failures(result["parity"], PARITY_BOUNDS_F64 if f64 else None)
+        if bad:
+            result["parity"]["failed"] = bad
 
         if cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_block(np, po, wl, ins[0], frames)
@@ -318,15 +412,37 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     return result
 
 
+# Vector-issue utilisation of the dominant kernel: wave64 VALU instructions per launch (a
+# property of the code and the launch shape, counted once by rocprofv3 --pmc SQ_INSTS_VALU and
+# committed in profiles/valu_insts.json) x 2 issue cycles for the plain f32 instructions (the
+# conversions take 4: counted as two slots there) / the SIMD-cycles the launch lasted (4 SIMDs per
+# CU x CUs x launch time x the shader clock under load, committed beside the count).
+def valu_issue_frac(name, avg_launch_s, cu_count):
+    path = os.path.join(ROOT, "profiles", "valu_insts.json")
+    try:
+        rec = json.load(open(path)).get(name)
+    except Exception:
+        rec = None
+    if not rec:
+        return None
+    simd_cycles = 4 * cu_count * avg_launch_s * rec["sclk_ghz_under_load"] * 1e9
+    return {"valu_issue_frac": rec["issue_slots_per_launch"] * 2.0 / simd_cycles,
+            "valu_issue_source": "profiles/valu_insts.json (SQ_INSTS_VALU per launch and sclk under load, "
+                                 "committed) x this run's launch duration"}
+
+
 def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
     """The f64 oracle on this host's cores over a bounded sample of buffer set 0:
     one thread for 3 s, then every core of the job's CPU share for 1.5 s
      -- about 27 CPU-seconds in all."""
     n_fft, k_avg, window, output, cic_r, _ = wl
     nproc = os.cpu_count()
-    # the GPU box gives one GPU's job a 16-CPU share whatever nproc says
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    sample = min(frames, 16384 if n_fft <= 1024 else 4096)
+    # every core this process may run on (its affinity mask): the node's cores, not a guess at
+    # the job's share -- if a cgroup quota throttles them, the figure shows it
+    cores = len(os.sched_getaffinity(0))
+    base = 16384 if n_fft <= 1024 else 4096
+    # enough rows that every thread has >= 64 frames between its creation and its join
+    sample = min(frames, max(base, 64 * cores))
     sample -= sample % k_avg
     host = dev_in[:sample].cpu().numpy()
 
@@ -359,12 +475,17 @@ def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
                 "sample": "%d x %d decimated outputs of buffer set 0, %d repetitions, cic_decimate of %s"
                           % (sample, n_fft, reps, "the reference's src/resample.c (oracle/_ref)"
                              if po.ref_available() else "oracle/rtlws_oracle.c")}
-    one_n = max(k_avg, (sample // 8) - (sample // 8) % k_avg)
+    one_n = max(k_avg, (min(sample, base) // 8) - (min(sample, base) // 8) % k_avg)
     v1, reps1 = timed(1, one_n, 3.0 * budget_scale)             # 3 CPU-seconds
-    vall, repsall = timed(cores, sample, 1.5 * budget_scale)    # 1.5 s on every core: <= 24 CPU-seconds
+    vall, repsall = timed(cores, sample, 1.5 * budget_scale)    # 1.5 s on every core of the mask
+    # a one-GPU job on the GPU box is given a 16-CPU share of the node whatever the mask says:
+    # the same code on 16 threads beside it (round 2's figure), so a throttled full-mask run reads as such
+    v16, reps16 = (timed(16, min(sample, base), 0.75 * budget_scale) if cores > 16 else (vall, repsall))
     return {"value": vall, "unit": "spectra/s", "cores": cores, "kind": "port", "nproc": nproc,
             "one_thread": {"value": v1, "unit": "spectra/s", "cores": 1,
                            "sample": "%d frames of buffer set 0, %d repetitions" % (one_n, reps1)},
+            "sixteen_threads": {"value": v16, "unit": "spectra/s", "cores": min(16, cores),
+                                "sample": "%d frames of buffer set 0, %d repetitions" % (min(sample, base), reps16)},
             "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
                       "(oracle/rtlws_oracle.c) on %d pthreads; one_thread: the same code on 1"
                       % (sample, frames, repsall, cores)}
@@ -430,7 +551,10 @@ def main(argv=None):
 
     eng = rtlws.Engine(local_rank)
     ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
-           "rank": rank, "device": device}
+           "rank": rank, "device": device,
+           # ONE side stream carries input synthesis and every launch (run_workload, "Stream order")
+           "stream": torch.cuda.Stream(device=device),
+           "cu_count": torch.cuda.get_device_properties(device).multi_processor_count}
 
     # First collective = RCCL's lazy communicator set-up (~16 ms): do it here, not
     # between the warm-up launches and the timed region, where that much idle
@@ -454,12 +578,35 @@ def main(argv=None):
                            "roofline": r["roofline"], "parity": r["parity"]})
         result["extra_workloads"] = extras
 
+    rc = 0
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        # A parity block that is non-finite or over its bound is a FAILED run: the line is still
+        # printed (strict JSON: a non-finite number becomes a string), the exit code says so.
+        blocks = [(result["config"]["workload"], result["parity"])]
+        blocks += [(x["workload"], x["parity"]) for x in result.get("extra_workloads", [])]
+        failed = {n: b["failed"] for n, b in blocks if b.get("failed")}
+        if failed:
+            result["parity_failed"] = failed
+            print("bench.py: PARITY FAILED on %s -- the timed launches did not reproduce the oracle"
+                  % json.dumps(failed), file=sys.stderr)
+            rc = 4
+        print(json.dumps(strict_json(result), allow_nan=False), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc
+
+
+def strict_json(x):
+    """NaN / inf have no JSON spelling: replace them by strings, recursively."""
+    import math
+    if isinstance(x, float) and not math.isfinite(x):
+        return repr(x)
+    if isinstance(x, dict):
+        return {k: strict_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [strict_json(v) for v in x]
+    return x
 
 
 if __name__ == "__main__":

@@ -3,8 +3,8 @@
  * the batch API that the roofline configurations use.
  *
  * Everything here is plain C: pointers, sizes, ints.  No HIP or torch types
- * appear in a signature; a stream is passed as `void*` (a hipStream_t, e.g.
- * torch.cuda.current_stream().cuda_stream, or NULL for the engine's own).
+ * appear in a signature; a stream is passed as `void*` (a hipStream_t; see
+ * "Streams" below for what NULL means -- it is NOT HIP's default stream).
  *
  * Why a batch API exists at all: the reference interface
  * (src/spectrum.h:11-15) hands over one N-sample frame per call and wants
@@ -35,6 +35,29 @@ extern "C" {
 
 typedef struct rtlws_engine rtlws_engine;
 
+/* ---- Streams -------------------------------------------------------------
+ *
+ * Every asynchronous entry point takes a `void* stream`:
+ *   a non-zero hipStream_t   the work is enqueued on exactly that stream;
+ *   RTLWS_STREAM_ENGINE      (NULL) the ENGINE'S OWN stream.  It is created with
+ *                            hipStreamNonBlocking, so it is NOT ordered against
+ *                            HIP's default (null) stream: work the caller queued
+ *                            on the default stream -- filling d_in, say -- may
+ *                            still be running when the kernel starts, and memory
+ *                            a stream-ordered allocator recycled on the default
+ *                            stream may be written while its previous user is
+ *                            still reading it.  Use rtlws_stream_sync(e, NULL) /
+ *                            events to order against it;
+ *   RTLWS_STREAM_DEFAULT     HIP's legacy default stream itself (hipStreamLegacy).
+ *
+ * The trap this spells out: torch.cuda.current_stream().cuda_stream is 0 for
+ * torch's default stream, the same bits as NULL.  A torch caller on the default
+ * stream passes RTLWS_STREAM_DEFAULT (rtlws.torch_stream_handle() does), or runs
+ * producer and launches on one torch.cuda.Stream() (non-zero handle), as bench.py
+ * does. */
+#define RTLWS_STREAM_ENGINE  ((void*)0)
+#define RTLWS_STREAM_DEFAULT ((void*)1)
+
 /* ---- engine / device plumbing ---------------------------------------- */
 
 /* Number of usable HIP devices (0 when none; never negative). */
@@ -60,7 +83,7 @@ void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes);
 void rtlws_dev_free(rtlws_engine* e, void* dptr);
 void* rtlws_pinned_alloc(size_t bytes);
 void rtlws_pinned_free(void* hptr);
-/* Asynchronous on `stream` (NULL: the engine's stream). 0 on success. */
+/* Asynchronous on `stream` (NULL: the engine's own non-blocking stream, see "Streams"). 0 on success. */
 int rtlws_copy_h2d(rtlws_engine* e, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int rtlws_copy_d2h(rtlws_engine* e, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int rtlws_memset_dev(rtlws_engine* e, void* dst_dev, int value, size_t bytes, void* stream);
@@ -125,7 +148,8 @@ typedef struct rtlws_spectra_desc {
  * d_out: (nframes / k_avg) rows of n_fft outputs, device memory.
  * nframes must be a multiple of k_avg; d_in and d_out 16-byte aligned
  * (any hipMalloc pointer, or one offset by whole frames / rows).
- * Asynchronous on `stream`.
+ * Asynchronous on `stream` (NULL = the engine's own stream, which is not ordered
+ * against HIP's default stream: "Streams" above).
  * Returns 0; -1 bad descriptor/size; -3 HIP failure (see rtlws_last_error). */
 int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
                         long nframes, void* d_out, void* stream);

@@ -214,8 +214,11 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
     return 0;
 }
 
+// include/rtlws_hip.h "Streams": NULL = the engine's own non-blocking stream,
+// RTLWS_STREAM_DEFAULT = HIP's legacy default stream, anything else = that stream.
 hipStream_t pick_stream(rtlws_engine* e, void* stream)
 {
+    if (stream == RTLWS_STREAM_DEFAULT) return hipStreamLegacy;
     return stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
 }
 

@@ -195,6 +195,18 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+STREAM_ENGINE, STREAM_DEFAULT = None, 1     # include/rtlws_hip.h "Streams"
+
+
+def torch_stream_handle(stream=None):
+    """The `stream` argument for a torch caller: torch's default stream has handle 0, which
+    the C-ABI reads as "the engine's own non-blocking stream" (NOT ordered against torch's
+    kernels) -- so 0 is mapped to RTLWS_STREAM_DEFAULT, HIP's default stream itself."""
+    import torch
+    h = (torch.cuda.current_stream() if stream is None else stream).cuda_stream
+    return h if h else STREAM_DEFAULT
+
+
 def make_desc(n_fft, k_avg=1, input="cu8", window="rect", output="power_sum", cic_r=0, gain_db=0):
     return SpectraDesc(int(n_fft), int(k_avg), _INPUTS.get(input, input), _WINDOWS.get(window, window),
                        _OUTPUTS.get(output, output), int(cic_r), int(gain_db), 0)

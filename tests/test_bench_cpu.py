@@ -25,6 +25,8 @@ def test_workload_table_is_consistent():
     assert bench.algorithmic_bytes_per_frame(2048, 1, 12) == 2 * 2048 * 12 + 4 * 2048
     assert bench.algorithmic_bytes_per_frame(1024, 6, 0, "payload_u8") == 2048 + 1024 // 6
     assert bench.algorithmic_bytes_per_frame(2048, 1, 8, "cs32") == 2 * 2048 * 8 + 8 * 2048
+    assert bench.algorithmic_bytes_per_frame(1024, 1, 0, "power_sum", f64=True) == 10240   # 2N + 8N/K
+    assert set(bench.F64_WORKLOADS) <= set(bench.WORKLOADS)
 
 
 @pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt",
@@ -68,9 +70,52 @@ def test_cpu_baseline_block_bookkeeping(oracle):
     dev_in = torch.from_numpy(synth.tone_noise_iq(256, 1024, seed=5))
     out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 256, budget_scale=0.02)
     assert out["unit"] == "spectra/s" and out["kind"] == "port" and out["nproc"] == os.cpu_count()
-    assert 1 <= out["cores"] <= 16 and out["value"] > 0
+    assert out["cores"] == len(os.sched_getaffinity(0)) and out["value"] > 0     # the whole mask, uncapped
     assert out["one_thread"]["cores"] == 1 and out["one_thread"]["value"] > 0
     wl = bench.WORKLOADS["cic8_block_sums"]
     dev_in = torch.from_numpy(synth.uniform_iq(8, 2048 * 8, seed=6))
     out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 8, budget_scale=0.02)
     assert out["unit"] == "samples/s" and out["cores"] == 1 and out["value"] > 0
+
+
+def test_parity_block_names_constant_input_rows_instead_of_dividing_by_zero(oracle):
+    """the driver's cic12 block was 0/0 = NaN with exit code 0.  A constant
+    input frame (all-zero oracle row) must be reported as such and fail the run."""
+    import bench
+    from rtlws import synth
+    wl = bench.WORKLOADS["cic12_2048pt"]
+    iq = synth.tone_noise_iq(4, 2048 * 12, seed=9)
+    iq[2] = 255                                    # what a clobbered synthesis temporary produces
+    ref = oracle.batch_spectra_cic_u8(iq, 2048, 12)
+    with np.errstate(all="raise"):                 # no 0/0 anywhere
+        out = bench.parity_block(np, oracle, wl, iq, ref.astype(np.float32), 4)
+    assert out["non_finite"] and out["constant_input_rows"] == [2]
+    assert out["input_byte_min_max_of_those_rows"] == [[255, 255]]
+    assert bench.parity_failures(out) == ["constant_input_rows"]
+
+
+def test_parity_failures_and_strict_json():
+    import json
+    import bench
+    ok = {"frames": 256, "max_rel_err_floor1e-5": 4e-5, "max_rel_err_floor1e-9": 4e-4, "p99.9_rel_err_floor1e-9": 3e-5}
+    assert bench.parity_failures(ok) == []
+    assert bench.parity_failures(dict(ok, **{"p99.9_rel_err_floor1e-9": 2e-4})) == ["p99.9_rel_err_floor1e-9"]
+    assert bench.parity_failures(dict(ok, **{"max_rel_err_floor1e-9": float("nan")})) == ["max_rel_err_floor1e-9"]
+    assert bench.parity_failures({"frames": 8, "bit_exact": False}) == ["bit_exact"]
+    assert bench.parity_failures({"frames": 8, "max_abs_db_err": 1e-3}) == ["max_abs_db_err"]
+    assert bench.parity_failures({"max_rel_err_floor1e-9": 3e-5}, bench.PARITY_BOUNDS_F64) == ["max_rel_err_floor1e-9"]
+    line = json.dumps(bench.strict_json({"a": float("nan"), "b": [1.0, float("inf")], "c": {"d": 2}}), allow_nan=False)
+    assert json.loads(line) == {"a": "nan", "b": [1.0, "inf"], "c": {"d": 2}}
+
+
+def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
+    import json
+    import bench
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "valu_insts.json").write_text(json.dumps(
+        {"w": {"issue_slots_per_launch": 4.0e7, "sclk_ghz_under_load": 2.0}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    out = bench.valu_issue_frac("w", 80e-6, 256)
+    # 4e7 slots x 2 cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
+    assert abs(out["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.0e9)) < 1e-12
+    assert bench.valu_issue_frac("other", 80e-6, 256) is None

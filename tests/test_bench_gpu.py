@@ -1,0 +1,90 @@
+"""bench.py's timed step itself on the GPU (the driver's line carried a
+NaN parity block and no test ran run_workload): every default-line workload at a small
+frame count must come back with a finite parity block inside its bounds, twice in a row
+with identical numbers, and the line must be strict JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    eng = built.Engine(0)
+    yield {"torch": torch, "np": np, "rtlws": built, "eng": eng, "dist": None, "world": 1, "rank": 0,
+           "device": dev, "stream": torch.cuda.Stream(device=dev),
+           "cu_count": torch.cuda.get_device_properties(dev).multi_processor_count}
+    eng.close()
+
+
+def _small_frames(bench, name):
+    n_fft, k_avg, _, _, cic_r, _ = bench.WORKLOADS[name]
+    return 512 * k_avg if n_fft * max(cic_r, 1) <= 8192 else 264 * k_avg
+
+
+@pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt",
+                                  "cic10_2048pt", "k6_1024pt_payload", "cic8_block_sums",
+                                  "batched_1024pt_64k_frames_f64"])
+def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "SETTLE_LAUNCHES", 40)        # the ordering matters here, not the governor
+    f64 = name in bench.F64_WORKLOADS
+    runs = [bench.run_workload(ctx, name, steps=8, warmup=0, sets=4, frames_override=_small_frames(bench, name))
+            for _ in range(2)]
+    for r in runs:
+        par = r["parity"]
+        assert "failed" not in par and not par.get("non_finite"), par
+        assert bench.parity_failures(par, bench.PARITY_BOUNDS_F64 if f64 else None) == []
+        json.loads(json.dumps(bench.strict_json(r), allow_nan=False))          # strict JSON
+        roof = r["roofline"]
+        assert roof["frac_clock"] == "hip_events_on_launch_stream" and roof["frac_wall"] > 0
+        assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
+        assert r["dtype"] == ("int32" if name == "cic8_block_sums" else ("f64" if f64 else "f32"))
+    assert runs[0]["parity"] == runs[1]["parity"]             # same seed, same kernel: identical statistics
+
+
+def test_torch_default_stream_handle_is_mapped(built):
+    import torch
+    assert torch.cuda.current_stream().cuda_stream == 0       # the trap: same bits as "engine's own stream"
+    assert built.torch_stream_handle() == built.STREAM_DEFAULT == 1
+    side = torch.cuda.Stream()
+    assert built.torch_stream_handle(side) == side.cuda_stream != 0
+
+
+def test_launch_on_hip_default_stream_is_ordered_with_torch(built, oracle):
+    """RTLWS_STREAM_DEFAULT: the kernel is enqueued on HIP's default stream, i.e. after the
+    torch kernels that produce its input and before the ones that consume its output -- with
+    no synchronisation in between."""
+    import torch
+    from rtlws import synth
+    dev = torch.device("cuda", 0)
+    eng = built.Engine(0)
+    N, nframes = 1024, 4096
+    host = synth.tone_noise_iq(nframes, N, seed=21)
+    staged = torch.from_numpy(host).to(dev)
+    desc = built.make_desc(N)
+    for _ in range(3):
+        iq = torch.zeros_like(staged)
+        out = torch.full((nframes, N), -1.0, dtype=torch.float32, device=dev)
+        big = torch.randn(1 << 26, device=dev)                # keep the default stream busy in front
+        big = big * 1.0001 + 1.0
+        iq.copy_(staged)                                      # producer, default stream
+        eng.spectra_batch(desc, iq.data_ptr(), nframes, out.data_ptr(), stream=built.torch_stream_handle())
+        total = out.sum(dtype=torch.float64)                  # consumer, default stream
+        got = out.cpu().numpy()
+        assert (got >= 0).all()                               # no row still holds the -1 fill
+        assert np.isclose(float(total), got.astype(np.float64).sum(), rtol=1e-9)   # the consumer saw the result
+        ref = oracle.batch_spectra_u8(host[:64], N)
+        rel = np.abs(got[:64] - ref) / np.maximum(ref, 1e-5 * ref.max(axis=1, keepdims=True))
+        assert rel.max() <= 1e-4
+    eng.close()

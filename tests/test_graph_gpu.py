@@ -28,7 +28,7 @@ def test_capture_and_replay(built, oracle):
         with torch.cuda.graph(g, stream=side):
             for i in range(launches):
                 eng.spectra_batch(desc, iq[i].data_ptr(), nframes, out[i].data_ptr(),
-                                  stream=torch.cuda.current_stream().cuda_stream)
+                                  stream=built.torch_stream_handle())
     torch.cuda.current_stream().wait_stream(side)
     assert float(out.abs().sum()) == 0.0            # capture enqueued nothing
     g.replay()
@@ -42,7 +42,7 @@ def test_capture_and_replay(built, oracle):
     assert rel_err(out[3].cpu().numpy(), ref, EPS_K1).max() <= TOL
     eager = torch.zeros((nframes, N), dtype=torch.float32, device=dev)
     eng.spectra_batch(desc, iq[3].data_ptr(), nframes, eager.data_ptr(),
-                      stream=torch.cuda.current_stream().cuda_stream)
+                      stream=built.torch_stream_handle())
     torch.cuda.synchronize()
     assert torch.equal(eager, out[3])
     eng.close()

@@ -26,7 +26,7 @@ for a in range(0, nframes, 1 << 18):
 out = torch.empty((nframes, N), dtype=torch.float32, device=dev)
 eng = rtlws.Engine(0)
 desc = rtlws.make_desc(N)
-eng.spectra_batch(desc, iq.data_ptr(), nframes, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+eng.spectra_batch(desc, iq.data_ptr(), nframes, out.data_ptr(), stream=rtlws.torch_stream_handle())
 torch.cuda.synchronize()
 rows = sorted(set([0, 1, 2, 1048575, 1048576, 1048577, 2097151, 2097152, 524287, 524288, nframes - 2, nframes - 1] +
                   list(np.random.default_rng(0).integers(0, nframes, 64))))

@@ -19,7 +19,7 @@ import rtlws      # noqa: E402
 dev = torch.device("cuda", 0)
 eng = rtlws.Engine(0)
 L = rtlws.hip_lib()
-stream = torch.cuda.current_stream().cuda_stream
+stream = rtlws.torch_stream_handle()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 RS = [int(a) for a in sys.argv[2:]] or [8, 10, 12, 5, 16]
 print('N=%d  RTLWS_CIC_DIRECT=%s' % (N, os.environ.get('RTLWS_CIC_DIRECT', '0')))

@@ -15,7 +15,7 @@ import rtlws      # noqa: E402
 dev = torch.device("cuda", 0)
 eng = rtlws.Engine(0)
 L = rtlws.hip_lib()
-stream = torch.cuda.current_stream().cuda_stream
+stream = rtlws.torch_stream_handle()
 RS = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 5, 8, 10, 12, 16, 25, 64, 127, 128]
 for R in RS:
     n_out = (1 << 27) // max(R, 4)

@@ -23,7 +23,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 65536 * 1024 // N
 dev = torch.device("cuda", 0)
 eng = rtlws.Engine(0)
-stream = torch.cuda.current_stream().cuda_stream
+stream = rtlws.torch_stream_handle()
 desc = rtlws.make_desc(N)
 src = [torch.randint(0, 256, (frames, N, 2), dtype=torch.uint8, device=dev) for _ in range(3)]
 dst = [torch.empty((frames, N), dtype=torch.float32, device=dev) for _ in range(3)]

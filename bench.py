@@ -56,6 +56,8 @@ WORKLOADS = {
     # the other fused sizes of the batch API, reference behaviour (rectangular, K = 1)
     "rect_2048pt": (2048, 1, "rect", "power_sum", 0, 32768),
     "rect_4096pt": (4096, 1, "rect", "power_sum", 0, 16384),
+    "hann_4096pt_k1_db": (4096, 1, "hann", "mean_db", 0, 16384),          # configs[2] without the averaging
+    "rect_4096pt_k8": (4096, 8, "rect", "power_sum", 0, 16384),           # ... without the window
     # the product's own averaging (src/cbb_main.c:18: 6 frames per estimate), byte payload out
     "k6_1024pt_payload": (1024, 6, "rect", "payload_u8", 0, 65536 - 65536 % 6),
     # stand-alone CIC (reference src/resample.c:6-45): "frame" = 2048 decimated outputs,

@@ -112,7 +112,7 @@ constexpr bool fused_kone_kind(int in_kind)
     return in_kind == IN_CU8 || in_kind == IN_CU8_CIC8 || in_kind >= IN_CU8_CIC10;
 }
 constexpr int fused_lds_f2(int n_fft);
-constexpr int fused_lds_bytes(int n_fft, int in_kind);
+constexpr int fused_lds_bytes(int n_fft, int in_kind, bool win = false);
 constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 {
     const bool acc_and_prefetch = !kone && fused_kone_kind(in_kind);
@@ -135,7 +135,7 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
                         : (n_fft == 2048 && !win && in_kind >= IN_CU8_CIC8 && !acc_and_prefetch) ? 4
                         : RTLWS_WAVES_BIG;
     // workgroups per CU that fit the 160 KiB LDS, n_fft/1024 wavefronts each, over 4 SIMDs
-    const int by_lds = (163840 / fused_lds_bytes(n_fft, in_kind)) * (n_fft / 1024) / 4;
+    const int by_lds = (163840 / fused_lds_bytes(n_fft, in_kind, win)) * (n_fft / 1024) / 4;
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 
@@ -147,6 +147,18 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 #endif
 constexpr bool fused_prefetch_u8(int n_fft, bool win) { return RTLWS_PREFETCH_4096WIN || !(n_fft == 4096 && win); }
 
+// ... those kernels prefetch WITHOUT registers instead: the next frame's bytes are copied
+// into LDS by global_load_lds (LDS-DMA, two 1-KiB copies per wavefront and frame, double
+// buffered: 4*N bytes of LDS beside the transposition buffer) while the current frame is
+// transformed, and read back with sixteen ds_read_u16 per thread.  -DRTLWS_DMA_PF=0: off.
+#ifndef RTLWS_DMA_PF
+#define RTLWS_DMA_PF 1
+#endif
+constexpr bool fused_dma_prefetch(int n_fft, int in_kind, bool win)
+{
+    return RTLWS_DMA_PF && in_kind == IN_CU8 && !fused_prefetch_u8(n_fft, win);
+}
+
 // LDS the fused kernel needs, in float2 units: 16 (padded) rows + one spare slot
 // (layouts: spectrum_fused.hip, "LDS layouts").
 constexpr int fused_lds_f2(int n_fft)
@@ -154,12 +166,26 @@ constexpr int fused_lds_f2(int n_fft)
     return 16 * 18 * (n_fft / 256) + 2;     // transposition 2 is the larger of the two
 }
 // ... in bytes, by input kind: the CIC staging slices share the buffer and may be the larger need
-constexpr int fused_lds_bytes(int n_fft, int in_kind)
+constexpr int fused_lds_bytes(int n_fft, int in_kind, bool win)
 {
     const int tr = 8 * fused_lds_f2(n_fft);
     const int st = in_kind >= IN_CU8_CICR_LDS4 ? (n_fft / 1024) * cic_stage_wave_bytes(in_kind) : 0;
-    return st > tr ? st : tr;
+    const int pf = fused_dma_prefetch(n_fft, in_kind, win) ? 2 * 2 * n_fft : 0;     // two raw frames
+    return (st > tr ? st : tr) + pf;
 }
+
+// ---- spectrum_fused_v2.hip: 4096-point cmplx_u8 frames, two virtual threads per lane ----
+// LDS in float2 units: transposition 2 is the larger (q2 stride 290, q1 stride 18) + the DC slot
+constexpr int v2_lds_f2(int n_fft) { return n_fft == 4096 ? 15 * 290 + 15 * 18 + 16 + 2 : 0; }
+constexpr int v2_lds_bytes(int n_fft) { return 8 * v2_lds_f2(n_fft); }
+// 2 wavefronts per workgroup, 2 per SIMD (256 VGPRs): 4 workgroups per CU, which is also what the LDS holds
+constexpr int v2_blocks_per_cu(int n_fft) { return 163840 / v2_lds_bytes(n_fft) < 4 ? 163840 / v2_lds_bytes(n_fft) : 4; }
+// which descriptors take it (the shim may override with RTLWS_V2=0|1 for A/B runs)
+#ifndef RTLWS_V2_DEFAULT
+#define RTLWS_V2_DEFAULT 1
+#endif
+constexpr bool fused_v2_kind(int n_fft, int in_kind) { return n_fft == 4096 && in_kind == IN_CU8; }
+hipError_t launch_spectra_fused_v2_4096(const SpectraParams&, int blocks, hipStream_t);
 
 hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);
 hipError_t launch_spectra_fused_2048(const SpectraParams&, int in_kind, int blocks, hipStream_t);

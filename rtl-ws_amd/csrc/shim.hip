@@ -235,12 +235,25 @@ bool desc_ok(const rtlws_spectra_desc* d)
     return true;
 }
 
+// spectrum_fused_v2.hip (two virtual threads per lane) for the descriptors it covers.  By
+// default only K = 1 rows take it: measured +4..8 % there (rect_4096pt 0.532 -> 0.577 of the HBM
+// roofline, Hann K = 1 0.471 -> 0.496) and -1..-4 % with K = 8 accumulators, where both kernels
+// deliver the same points per second (DESIGN.md, configs[2]).  RTLWS_V2=0|1 forces either
+// kernel for every K (A/B runs, tests/test_v2_gpu.py); read per call.
+bool use_v2(int n_fft, int in_kind, int k_avg)
+{
+    if (!rtlws::fused_v2_kind(n_fft, in_kind)) return false;
+    const char* v = getenv("RTLWS_V2");
+    return (v && *v) ? (atoi(v) != 0) : (RTLWS_V2_DEFAULT != 0 && k_avg == 1);
+}
+
 int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0, bool win = false,
-                 bool kone = false)
+                 bool kone = false, int k_avg = 0)
 {
     // 4 x waves-per-SIMD wavefronts per CU, n_fft/1024 wavefronts per workgroup.
     // Persistent: each workgroup strides over the output rows.
     int per_cu = 4 * rtlws::fused_waves_per_simd(n_fft, in_kind, win, kone) / (n_fft / 1024);
+    if (use_v2(n_fft, in_kind, k_avg)) per_cu = rtlws::v2_blocks_per_cu(n_fft);
     if (const char* ov = getenv("RTLWS_BLOCKS_PER_CU")) {   // experiments only
         const int v = atoi(ov);
         if (v > 0) per_cu = v;
@@ -476,9 +489,10 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
         int in_kind = d->input;
         if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
-                                           d->k_avg == 1 && rtlws::fused_kone_kind(in_kind));
-        if (threads) *threads = d->n_fft / 16;
-        if (lds_bytes) *lds_bytes = rtlws::fused_lds_bytes(d->n_fft, in_kind);
+                                           d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
+        const bool v2 = use_v2(d->n_fft, in_kind, d->k_avg);
+        if (threads) *threads = v2 ? d->n_fft / 32 : d->n_fft / 16;
+        if (lds_bytes) *lds_bytes = v2 ? rtlws::v2_lds_bytes(d->n_fft) : rtlws::fused_lds_bytes(d->n_fft, in_kind, d->window == RTLWS_WIN_HANN);
     } else {
         if (blocks) *blocks = (int)ngroups;
         if (threads) *threads = 256;
@@ -533,11 +547,14 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     hipError_t err;
     if (fused) {
         const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
-                                        d->k_avg == 1 && rtlws::fused_kone_kind(in_kind));
+                                        d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
         switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
         case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;
-        default: err = rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st); break;
+        default:
+            err = use_v2(d->n_fft, in_kind, d->k_avg) ? rtlws::launch_spectra_fused_v2_4096(p, blocks, st)
+                                            : rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st);
+            break;
         }
     } else {
         if (in_kind >= rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8;     // the direct kernel sums R bytes itself

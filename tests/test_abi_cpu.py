@@ -3,6 +3,7 @@ declares (no compute calls: there is no GPU here), and fail loudly without one."
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -122,3 +123,35 @@ def test_no_kernel_spills_registers(built):
     # the headline kernel keeps its 4 waves/SIMD (<= 128 VGPRs)
     head = [k for k in fused if "spectra_fused<1024, 0, false, 0, true>" in k.get("demangled", "")]
     assert len(head) == 1 and head[0]["vgpr_count"] <= 128
+
+
+def test_v2_pass3_lane_map_is_a_conflict_free_permutation():
+    """spectrum_fused_v2.hip pair_of_lane(): a permutation of the 128 pairs, and with the
+    transposition-2 strides (290, 18) every ds_read_b128 lane group covers the 64 banks once
+    (tools/lds_sim.py's bank model, MI355X_MICROARCH.md LDS table)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    argv = sys.argv
+    sys.argv = ["lds_sim"]
+    try:
+        import lds_sim
+    finally:
+        sys.argv = argv
+
+    def pair_of_lane(t):
+        l = t & 31
+        s = l if l < 4 else l + 12 if l < 12 else l - 8 if l < 16 else l + 8 if l < 20 else l - 12 if l < 28 else l
+        return (t & ~31) | s
+
+    assert sorted(pair_of_lane(t) for t in range(128)) == list(range(128))
+    assert pair_of_lane(0) == 0 and pair_of_lane(127) == 127          # the DC-slot hand-off relies on both
+    total = 0
+    for wave in range(2):
+        lanes = [64 * wave + l for l in range(64)]
+        for h in range(2):
+            for i in range(8):
+                addr = [(pair_of_lane(t) >> 3) * 290 + (2 * (pair_of_lane(t) & 7) + h) * 18 + 2 * i for t in lanes]
+                assert all(a % 2 == 0 for a in addr)                  # 16-byte aligned
+                total += lds_sim.cycles(addr, lds_sim.R128, 4, 64)
+    assert total == 2 * 16 * 4                                        # 4 LDS cycles per instruction: no conflict
+    res = lds_sim.analyse_v2(4096, 272, 290, 18, verbose=False)
+    assert all(r[:3] == (128, 64, 128) for r in res.values())         # writes and the pass-2 reads as well

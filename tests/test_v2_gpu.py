@@ -1,0 +1,56 @@
+"""spectrum_fused_v2.hip (two virtual threads per lane, 4096-point cmplx_u8 frames) against
+the four-wavefront kernel it replaces: the arithmetic is the same instruction for
+instruction, so every output must be BIT-identical, for every window / K / output mode --
+and both are held to the oracle by the rest of the suite (which now runs the v2 kernel
+wherever it applies)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(engine, iq, **kw):
+    old = os.environ.get("RTLWS_V2")
+    try:
+        os.environ["RTLWS_V2"] = "1"
+        a = engine.spectra(iq, 4096, **kw)
+        os.environ["RTLWS_V2"] = "0"
+        b = engine.spectra(iq, 4096, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("RTLWS_V2", None)
+        else:
+            os.environ["RTLWS_V2"] = old
+    return a, b
+
+
+@pytest.mark.parametrize("window", ["rect", "hann"])
+@pytest.mark.parametrize("k_avg,output", [(1, "power_sum"), (8, "mean_db"), (6, "payload_u8"), (3, "power_sum")])
+def test_v2_bit_identical_to_the_four_wavefront_kernel(engine, built, window, k_avg, output):
+    from rtlws import synth
+    rows = 1031                                   # more rows than resident workgroups: the persistent loop strides
+    iq = synth.tone_noise_iq(rows * k_avg, 4096, seed=11 + k_avg)
+    iq[5] = 128                                   # a constant frame (all bins zero)
+    iq[7] = synth.uniform_iq(1, 4096, seed=3)[0]
+    desc = built.make_desc(4096, k_avg, "cu8", window, output)
+    os.environ["RTLWS_V2"] = "1"
+    try:
+        rc, blocks, threads, lds = engine.grid(desc, rows * k_avg)
+    finally:
+        os.environ.pop("RTLWS_V2", None)
+    assert (rc, threads) == (0, 128) and lds == 8 * (15 * 290 + 15 * 18 + 18) and blocks <= 4 * 256
+    a, b = _both(engine, iq, k_avg=k_avg, window=window, output=output)
+    assert a.shape == (rows, 4096)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_v2_small_and_ragged_grids(engine, oracle):
+    from rtlws import synth
+    from helpers import rel_err, EPS_K1, TOL
+    for rows in (1, 2, 5):
+        iq = synth.tone_noise_iq(rows, 4096, seed=rows)
+        a, b = _both(engine, iq)
+        assert np.array_equal(a, b)
+        assert rel_err(a, oracle.batch_spectra_u8(iq, 4096), EPS_K1).max() <= TOL

@@ -228,3 +228,42 @@ def check_swizzled_1024():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "check":
     check_swizzled_1024()
+
+
+# ---- two virtual threads per lane (spectrum_fused_v2.hip): lane t owns vt = 2t, 2t+1 ----
+W128 = [list(range(8 * g, 8 * g + 8)) for g in range(8)]     # ds_write_b128: 8 x 8 contiguous lanes, banks mod 32
+
+
+def analyse_v2(N, S1, A2, P2, verbose=True):
+    """lds1(q1, m1) = q1*S1 + m1; lds2(q1, m2, q2) = q2*A2 + (q1//J)*P2 + (q1%J)*R3 + m2.
+    Every access is 16 bytes: the two virtual threads of a lane are adjacent in m1 / m2."""
+    T, R3 = N // 16, N // 256
+    J = 16 // R3
+    TR = T // 2
+    tot = {}
+    for wave in range(max(1, TR // 64)):
+        lanes = [wave * 64 + l for l in range(64)]
+        # write 1: fixed s, lane t writes (rev16(s), 2t..2t+1)
+        w1 = sum(cycles([rev16(s) * S1 + 2 * t for t in lanes], W128, 4, 32) for s in range(16))
+        # read 1: fixed r2; vt = 2t + h: q1 = vt // R3, m2 = vt % R3 (h adjacent)
+        r1 = sum(cycles([((2 * t) // R3) * S1 + R3 * r2 + (2 * t) % R3 for t in lanes], R128, 4, 64) for r2 in range(16))
+        # write 2: fixed s (q2 = rev16(s)); (q1, m2) as above
+        def l2(q1, m2, q2):
+            return q2 * A2 + (q1 // J) * P2 + (q1 % J) * R3 + m2
+        w2 = sum(cycles([l2((2 * t) // R3, (2 * t) % R3, rev16(s)) for t in lanes], W128, 4, 32) for s in range(16))
+        # read 2: virtual thread (q2, g3) = (vt // R3, vt % R3) reads its 16 contiguous elements, 8 x b128, per h
+        r2c = 0
+        for h in range(2):
+            for i in range(8):
+                r2c += cycles([l2(J * ((2 * t + h) % R3), 0, (2 * t + h) // R3) + 2 * i for t in lanes], R128, 4, 64)
+        tot[wave] = (w1, r1, w2, r2c)
+        if verbose:
+            print("N=%d v2 wave %d: write1 %d (ideal 128) read1 %d (64) write2 %d (128) read2 %d (64)"
+                  % (N, wave, w1, r1, w2, r2c))
+    return tot
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "v2":
+    for N in (2048, 4096):
+        T, R3 = N // 16, N // 256
+        analyse_v2(N, T + R3, 18 * R3, 18)

@@ -70,7 +70,7 @@ WORKLOADS = {
 F64_WORKLOADS = ("batched_1024pt_64k_frames_f64",)
 HEADLINE = "batched_1024pt_64k_frames"
 # configs[2], configs[3] and the reference's own decimation factor ride along on the default line
-EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt")
+EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", "batched_1024pt_64k_frames_f64")
 EXTRA_STEPS = 200
 
 
@@ -575,7 +575,7 @@ def main(argv=None):
         for name in EXTRA_WORKLOADS:
             r = run_workload(ctx, name, EXTRA_STEPS, 0, args.sets)
             extras.append({"workload": name, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
-                           "steps": r["steps"], "settle_launches": r["settle_launches"],
+                           "dtype": r["dtype"], "steps": r["steps"], "settle_launches": r["settle_launches"],
                            "ms_per_step": r["ms_per_step"], "config": r["config"],
                            "roofline": r["roofline"], "parity": r["parity"]})
         result["extra_workloads"] = extras

@@ -87,7 +87,17 @@ struct SpectraParamsF64 {
     const double* window;  // [N] or nullptr
     double lin_gain;       // 10^(gain_db/10), C integer division (src/cbb_main.c:112)
     double in_scale;       // 1/128 or 1
+    // spectrum_f64_fused.hip (1024-point cmplx_u8 frames): the fused kernel's tables in double
+    const double2* tw1f;     // [64][16] scale * W_N^(t*rev16(s))
+    const double2* tw2f;     // [16][2] last-pass (cos, sin/cos) pairs
+    const double2* hann_csf; // [64] (0.5*cos, 0.5*sin)(2*pi*t/N)
 };
+
+// which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip)
+constexpr bool f64_fused_kind(int n_fft, int in_kind, int cic_r) { return n_fft == 1024 && in_kind == IN_CU8 && cic_r <= 1; }
+constexpr int f64_fused_lds_bytes() { return 16 * 68 * 16; }          // 16 padded rows of double2
+constexpr int f64_fused_blocks_per_cu() { return 8; }                  // 2 one-wavefront workgroups per SIMD
+hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int blocks, hipStream_t);
 
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
 // second argument), by instantiation, chosen so that NO instantiation spills

@@ -54,6 +54,9 @@ struct Tables {
     float2* hann_cs = nullptr;      // fused: [T] (0.5 cos, 0.5 sin)(2 pi t / N)
     double2* tw64 = nullptr;        // f64 kernel: W_N^k, k < N
     double* hann64 = nullptr;
+    double2* tw1_64 = nullptr;      // f64 fused kernel (N = 1024): [T][16] W_N^(t*rev16(s)) / 128
+    double2* tw2_64 = nullptr;      //   [16][R3/2] last-pass (cos, sin/cos) pairs
+    double2* hann_cs64 = nullptr;   //   [T] (0.5 cos, 0.5 sin)(2 pi t / N)
 };
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;
@@ -111,6 +114,9 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.hann_cs);
     (void)hipFree(tb.tw64);
     (void)hipFree(tb.hann64);
+    (void)hipFree(tb.tw1_64);
+    (void)hipFree(tb.tw2_64);
+    (void)hipFree(tb.hann_cs64);
     tb = Tables();
 }
 
@@ -208,6 +214,47 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
     if (!upload_table(hw, &tb.tw64) || !upload_table(hh, &tb.hann64)) {
         free_tables(tb);
         return -3;
+    }
+    if (n_fft == 1024) {
+        // the fused f64 kernel's tables: the f32 kernel's (get_tables), evaluated in long double
+        // and rounded once to double; the u8 input scale 1/128 folded into tw1 (exact)
+        const int T = n_fft / 16, R3 = n_fft / 256, NP = R3 / 2;
+        auto wn = [&](long num, long den, long double* c, long double* sn) {     // exp(-2 pi i num/den)
+            num %= den;
+            if (num == 0) { *c = 1.0L; *sn = 0.0L; }
+            else if (4 * num == den) { *c = 0.0L; *sn = -1.0L; }
+            else if (2 * num == den) { *c = -1.0L; *sn = 0.0L; }
+            else if (4 * num == 3 * den) { *c = 0.0L; *sn = 1.0L; }
+            else {
+                const long double a = -two_pi * (long double)num / (long double)den;
+                *c = cosl(a);
+                *sn = sinl(a);
+            }
+        };
+        std::vector<double2> h1((size_t)T * 16), h2((size_t)NP * 16), hcs((size_t)T);
+        for (int t = 0; t < T; ++t) {
+            for (int s = 0; s < 16; ++s) {
+                long double c, sn;
+                wn((long)t * rev16h(s), n_fft, &c, &sn);
+                h1[(size_t)t * 16 + s] = make_double2((double)(c * 0.0078125L), (double)(sn * 0.0078125L));
+            }
+            const long double a = two_pi * (long double)t / (long double)n_fft;
+            hcs[t] = make_double2((double)(0.5L * cosl(a)), (double)(0.5L * sinl(a)));
+        }
+        for (int q2 = 0; q2 < 16; ++q2) {
+            int k = 0;
+            for (int L = 2; L <= R3; L *= 2)
+                for (int pp = 0; pp < (L >= 4 ? L / 4 : 1); ++pp) {
+                    long double c, sn;       // alpha^(R3/L) * W_L^p = W_(T*L)^(q2*R3 + p*T), as (cos, sin/cos)
+                    wn((long)q2 * R3 + (long)pp * T, (long)T * L, &c, &sn);
+                    if (c == 0.0L) c = 1e-20L;
+                    h2[(size_t)q2 * NP + k++] = make_double2((double)c, (double)(sn / c));
+                }
+        }
+        if (!upload_table(h1, &tb.tw1_64) || !upload_table(h2, &tb.tw2_64) || !upload_table(hcs, &tb.hann_cs64)) {
+            free_tables(tb);
+            return -3;
+        }
     }
     e->tables[kF64Key + n_fft] = tb;
     *out = tb;
@@ -621,8 +668,28 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     p.lin_gain = std::pow(10.0, (double)(d->gain_db / 10));
     p.in_scale = (d->input != RTLWS_IN_RF32) ? 0.0078125 : 1.0;
 
+    p.tw1f = tb.tw1_64;
+    p.tw2f = tb.tw2_64;
+    p.hann_csf = tb.hann_cs64;
+
     HIP_TRY(hipSetDevice(e->device), -3);
-    hipError_t err = rtlws::launch_spectra_f64(p, d->input, pick_stream(e, stream));
+    hipError_t err;
+    // 1024-point cmplx_u8 frames: the fused throughput kernel (spectrum_f64_fused.hip);
+    // RTLWS_F64_FUSED=0 keeps them on the row-per-workgroup kernel (A/B runs, tests)
+    const char* ff = getenv("RTLWS_F64_FUSED");
+    if (rtlws::f64_fused_kind(d->n_fft, d->input, d->cic_r) && !(ff && ff[0] == '0') &&
+        !(reinterpret_cast<uintptr_t>(d_out) & 15u)) {
+        int per_cu = rtlws::f64_fused_blocks_per_cu();
+        if (const char* ov = getenv("RTLWS_F64_BLOCKS_PER_CU")) {   // experiments only
+            const int v = atoi(ov);
+            if (v > 0 && v <= 9) per_cu = v;
+        }
+        long blocks = (long)e->cu_count * per_cu;
+        if (blocks > p.ngroups) blocks = p.ngroups;
+        err = rtlws::launch_spectra_f64_fused_1024(p, (int)blocks, pick_stream(e, stream));
+    } else {
+        err = rtlws::launch_spectra_f64(p, d->input, pick_stream(e, stream));
+    }
     if (err != hipSuccess) {
         set_err("f64 spectra kernel launch", err);
         return -3;

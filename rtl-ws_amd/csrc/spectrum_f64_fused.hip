@@ -1,0 +1,258 @@
+// spectrum_f64_fused.hip -- 1024-point cmplx_u8 frames -> power spectra in DOUBLE, at
+// throughput: the batch form of what the reference computes per frame (src/spectrum.c:54-60
+// convert to double, :21 f64 forward DFT, :23-34 |X|^2 + fft-shift + accumulate + DC-slot
+// rule into a double buffer; K loop of src/cbb_main.c:50-59; dB / truncate / clamp of
+// src/cbb_main.c:121-130 in double, same operation order).
+//
+// The f32 fused kernel holds "<= 1e-4 relative" only against a floor 50 dB under a row's
+// maximum (f32 rounding next to a strong tone); the reference is f64 end to
+// end.  This kernel is the same radix-16 x 16 x 4 structure as spectrum_fused.hip at
+// N = 1024 -- one 64-lane wavefront per frame, sixteen complex points per lane, two
+// wave-private LDS transpositions, no barrier -- with every value a double: strict-metric
+// error (floor 1e-9 of the row maximum) ~1e-13, i.e. rtlws_spectra_batch_f64 at batch
+// rates instead of one workgroup-per-row radix-2 (spectrum_f64.hip, which keeps every
+// other N, the cmplx_s32 / real-f32 inputs and the CIC-fused form).
+//
+// Cost model (MI355X): v_fma_f64 / v_add_f64 / v_mul_f64 issue at 4 cycles per wave64
+// instruction -- half the f32 rate, and the rate ONE wavefront can issue at by itself, so 2
+// wavefronts per SIMD are enough; ~560 of them per frame = 560 CU-cycles at 4 SIMDs.
+// Algorithmic bytes: 2N in + 8N/K out = 10 240 B per spectrum at K = 1.
+//
+// LDS (double2 units, one buffer reused by both transpositions; tools/lds_sim.py f64):
+//   transposition 1  (q1, m1) at q1*68 + m1: rows of 64 padded to 68, so that the pass-2
+//       ds_read_b128 groups ({0-3,12-15,20-27}: rows 0,3,5,6 / {4-11,16-19,28-31}: rows
+//       1,2,4,7) land on four different 64-byte bank quarters;
+//   transposition 2  (q1, m2, q2) at q2*68 + (q1/4)*17 + (q1%4)*4 + m2: a reader lane's
+//       sixteen elements are contiguous, groups of 16 padded to 17.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtlws_internal.h"
+#include "fft_regs_f64.h"
+
+namespace rtlws {
+
+using namespace f64;      // f2 = double2, real = double, fft16_fma, fft_last, hann_w ... in double
+
+constexpr int F64F_N = 1024, F64F_T = 64, F64F_R3 = 4, F64F_J = 4;
+constexpr int F64F_ROW = 68;
+
+template <bool WIN, int OUT, bool KONE>
+__global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF64 p)
+{
+    constexpr int N = F64F_N, T = F64F_T, R3 = F64F_R3, J = F64F_J;
+    extern __shared__ __attribute__((aligned(16))) double2 ldsd[];
+
+    const int t = threadIdx.x;
+    const int K = KONE ? 1 : p.k_avg;
+    const long ngroups = p.ngroups;
+
+    // first frame's bytes first (sixteen 2-byte loads per lane, one 128-byte line per instruction)
+    unsigned raw[16];
+    auto load_raw = [&](long frame) {
+#ifdef RTLWS_F64_ABL_NOLOAD      // timing-only build: no HBM reads
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[r] = (unsigned)((frame * 131 + T * r + t) * 2654435761u >> 16) & 0xffffu;
+#else
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(p.in) + frame * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + T * r + t);
+#endif
+    };
+    if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
+
+    f2 tw1[16], tw3[R3 / 2];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tw1[s] = p.tw1f[t * 16 + s];
+#pragma unroll
+    for (int m = 0; m < R3 / 2; ++m) tw3[m] = p.tw2f[(t / R3) * (R3 / 2) + m];
+    // Hann weights from two lane constants (fft_regs_impl.h): sixteen registers pairs for K = 1;
+    // with K-frame accumulators beside them the 256-VGPR budget is 2 short, so that form
+    // regenerates them every frame (two FMAs each)
+    constexpr bool WINREGS = WIN && KONE;
+    f2 wcs = WIN ? p.hann_csf[t] : mk(0.0, 0.0);
+    double win[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) win[r] = WINREGS ? hann_w(r, wcs) : 1.0;
+#pragma unroll
+    for (int s = 1; s < 16; ++s) asm volatile("" ::"v"(tw1[s].x), "v"(tw1[s].y));
+    if constexpr (WINREGS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(win[r]));
+    }
+#pragma unroll
+    for (int m = 0; m < R3 / 2; ++m) asm volatile("" ::"v"(tw3[m].x), "v"(tw3[m].y));
+    const double in_scale = p.in_scale;
+
+    const int q1 = t / R3, m2 = t % R3;     // pass 2: (q1, m2); pass 3: (q2, g3) -- the same split
+
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        double acc[16];
+        double wdc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+
+        for (int kf = 0; kf < K; ++kf) {
+            const long frame = g * K + kf;
+            f2 v[16];
+            if constexpr (WIN && !WINREGS) asm volatile("" : "+v"(wcs.x), "+v"(wcs.y));   // not hoisted
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // (double)u8 is exact; the 128 offset is kept on the rectangular path (it only
+                // reaches bin 0, which is never output: src/spectrum.c:31) and folded into one
+                // FMA on the windowed one ((x - 128) * w, -128 * w exact)
+                const double re = (double)(raw[r] & 0xffu), im = (double)((raw[r] >> 8) & 0xffu);
+                if constexpr (WIN) {
+                    const double w = WINREGS ? win[r] : hann_w(r, wcs), c = -128.0 * w;
+                    v[r] = mk(fma(re, w, c), fma(im, w, c));
+                } else {
+                    v[r] = mk(re, im);
+                }
+            }
+            {
+                long nf = frame + 1;
+                if (kf + 1 == K) nf = (g + gridDim.x) * K;
+                if (nf >= ngroups * K) nf = frame;        // in bounds, result unused
+                load_raw(nf);
+            }
+
+            // ---- pass 1: radix-16 over the slow digit, twiddle W_N^(m1*q1) (carries the 1/128)
+            fft16_sel(v);
+            v[0] = mk(v[0].x * in_scale, v[0].y * in_scale);
+#pragma unroll
+            for (int s = 1; s < 16; ++s) v[s] = cmul(v[s], tw1[s]);
+
+#ifndef RTLWS_F64_ABL_NOLDS      // (timing-only build without the LDS traffic)
+            __syncthreads();   // one wavefront per workgroup: no s_barrier, only the LDS ordering
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ldsd[rev16(s) * F64F_ROW + t] = v[s];
+            __syncthreads();
+
+            // ---- pass 2: lane (q1, m2) holds y[q1][4*r2 + m2]
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) v[r2] = ldsd[q1 * F64F_ROW + R3 * r2 + m2];
+#endif
+            fft16_sel(v);
+#ifndef RTLWS_F64_ABL_NOLDS
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ldsd[rev16(s) * F64F_ROW + (t >> 4) * 17 + (t & 15)] = v[s];
+            __syncthreads();
+
+            // ---- pass 3: lane (q2, g3) = (t / 4, t % 4): sixteen contiguous elements, four
+            // twiddled radix-4 butterflies in fused-multiply-add form
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = ldsd[q1 * F64F_ROW + m2 * 17 + i];
+#endif
+#pragma unroll
+            for (int j = 0; j < J; ++j) fft_last<R3>(v, j * R3, tw3);
+
+            // ---- |X|^2, accumulate; slot u = j*4 + s holds bin k = 256*s + 4*t + j
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (u == 15) {      // bin N-1 (lane 63) also feeds the DC slot, weight K - kf
+                    const double pw = fma(v[u].y, v[u].y, v[u].x * v[u].x);
+                    acc[u] = KONE ? pw : acc[u] + pw;
+                    wdc = KONE ? pw : fma((double)(K - kf), pw, wdc);
+                } else if constexpr (KONE) {
+                    acc[u] = fma(v[u].y, v[u].y, v[u].x * v[u].x);
+                } else {
+                    acc[u] = fma(v[u].y, v[u].y, fma(v[u].x, v[u].x, acc[u]));
+                }
+            }
+        }
+
+        // ---- DC-slot rule (src/spectrum.c:25-33): slot N/2 (bin 0: lane 0, u = 0) takes
+        // sum_k (K-k) * P_k[N-1] (bin N-1: lane 63, u = 15)
+        {
+            const unsigned long long b = __builtin_bit_cast(unsigned long long, wdc);
+            const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, 63);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+            const double dcv = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            if (t == 0) acc[0] = dcv;
+        }
+
+        // ---- epilogue + store.  For each s the wavefront covers 256 consecutive outputs and a
+        // lane owns four of them (bins 4t .. 4t+3): 32 bytes, i.e. two 16-byte stores that would
+        // each leave every other 16 bytes of a line unwritten -- measured 1.58x the output bytes
+        // at the HBM and 286 us per launch against 100 us with no stores at all.  The rows of
+        // doubles therefore go through the (idle) transposition buffer once more, so that every
+        // store instruction writes 1 KiB of consecutive bytes: lane l the l-th 16 bytes.
+        // fft-shift = flip the top bit of the bin index.
+        if constexpr (OUT == OUT_PAYLOAD) {
+#pragma unroll
+            for (int s = 0; s < R3; ++s) {
+                const int i0 = 256 * (s ^ (R3 / 2)) + J * t;
+                unsigned packed = 0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    // src/cbb_main.c:125-128, same operation order, in double
+                    const double d = 10.0 * log10(fabs(p.lin_gain * acc[j * R3 + s] / (double)p.count));
+                    const unsigned m = (d >= 0.0) ? (d <= 255.0 ? (unsigned)(int)d : 255u) : 0u;
+                    packed |= m << (8 * j);
+                }
+                *reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(p.out) + g * N + i0) = packed;
+            }
+        } else {
+            __syncthreads();   // this row's pass-3 reads are done (wave-private: LDS ordering only)
+#pragma unroll
+            for (int s = 0; s < R3; ++s) {
+                double o[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    o[j] = acc[j * R3 + s];
+                    if constexpr (OUT == OUT_DB) o[j] = 10.0 * log10(o[j] / (double)p.count);
+                }
+                ldsd[128 * s + 2 * t] = mk(o[0], o[1]);
+                ldsd[128 * s + 2 * t + 1] = mk(o[2], o[3]);
+            }
+            __syncthreads();
+            typedef double nt_d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int s = 0; s < R3; ++s) {
+                nt_d2* dst = reinterpret_cast<nt_d2*>(reinterpret_cast<double*>(p.out) + g * N + 256 * (s ^ (R3 / 2)));
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const f2 x = ldsd[128 * s + 64 * half + t];
+                    const nt_d2 v2 = {x.x, x.y};
+#if defined(RTLWS_F64_ABL_NOSTORE)   // timing-only build: values kept live, nothing stored
+                    if (p.k_avg == 12345) dst[64 * half + t] = v2;
+                    else asm volatile("" ::"v"(x.x), "v"(x.y));
+#elif defined(RTLWS_F64_PLAIN_STORE)
+                    dst[64 * half + t] = v2;
+#else
+                    __builtin_nontemporal_store(v2, dst + 64 * half + t);
+#endif
+                }
+            }
+        }
+    }
+}
+
+template <bool WIN, int OUT>
+static hipError_t launch_f64f_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
+{
+    const size_t lds_bytes = f64_fused_lds_bytes();
+    if (p.k_avg == 1)
+        hipLaunchKernelGGL((spectra_f64_fused<WIN, OUT, true>), dim3(blocks), dim3(64), lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((spectra_f64_fused<WIN, OUT, false>), dim3(blocks), dim3(64), lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <bool WIN>
+static hipError_t launch_f64f_o(const SpectraParamsF64& p, int blocks, hipStream_t st)
+{
+    switch (p.out_mode) {
+    case OUT_SUM: return launch_f64f_k<WIN, OUT_SUM>(p, blocks, st);
+    case OUT_DB: return launch_f64f_k<WIN, OUT_DB>(p, blocks, st);
+    default: return launch_f64f_k<WIN, OUT_PAYLOAD>(p, blocks, st);
+    }
+}
+
+hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64& p, int blocks, hipStream_t st)
+{
+    return p.window ? launch_f64f_o<true>(p, blocks, st) : launch_f64f_o<false>(p, blocks, st);
+}
+
+}  // namespace rtlws

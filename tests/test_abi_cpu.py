@@ -110,7 +110,7 @@ def test_no_kernel_spills_registers(built):
     fused = [k for k in ks if "spectra_fused" in k["name"]]
     assert len(fused) >= 200                       # every (N, input, window, output, K==1) instantiation
     names = " ".join(k.get("demangled", "") for k in ks)
-    for want in ("spectra_f64", "spectra_direct", "cic8_kernel", "cicr_kernel", "halfband_kernel",
+    for want in ("spectra_f64", "spectra_f64_fused", "spectra_fused_v2", "spectra_direct", "cic8_kernel", "cicr_kernel", "halfband_kernel",
                  "fm_demod_kernel", "payload_kernel", "payload_f64_kernel"):
         assert want in names, want
     # (the f64 kernel parks scalar lane masks of its 32 unrolled slots in a VGPR --
@@ -123,6 +123,10 @@ def test_no_kernel_spills_registers(built):
     # the headline kernel keeps its 4 waves/SIMD (<= 128 VGPRs)
     head = [k for k in fused if "spectra_fused<1024, 0, false, 0, true>" in k.get("demangled", "")]
     assert len(head) == 1 and head[0]["vgpr_count"] <= 128
+    # the two-wavefronts-per-SIMD kernels stay inside their 256 registers without scratch
+    for k in ks:
+        if "spectra_fused_v2" in k["name"] or "spectra_f64_fused" in k["name"]:
+            assert k["vgpr_count"] <= 256 and not k.get("sgpr_spill_count", 0), k.get("demangled")
 
 
 def test_v2_pass3_lane_map_is_a_conflict_free_permutation():
@@ -155,3 +159,16 @@ def test_v2_pass3_lane_map_is_a_conflict_free_permutation():
     assert total == 2 * 16 * 4                                        # 4 LDS cycles per instruction: no conflict
     res = lds_sim.analyse_v2(4096, 272, 290, 18, verbose=False)
     assert all(r[:3] == (128, 64, 128) for r in res.values())         # writes and the pass-2 reads as well
+
+
+def test_f64_fused_lds_layout_is_conflict_free():
+    """spectrum_f64_fused.hip: rows of 64 double2 padded to 68, reader groups of 16 padded to 17."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    argv = sys.argv
+    sys.argv = ["lds_sim"]
+    try:
+        import lds_sim
+    finally:
+        sys.argv = argv
+    assert lds_sim.analyse_f64(68, 17, verbose=False) == (128, 64, 128, 64)
+    assert lds_sim.analyse_f64(64, 16, verbose=False)[1] > 64          # the unpadded layout conflicts

@@ -267,3 +267,24 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "v2":
     for N in (2048, 4096):
         T, R3 = N // 16, N // 256
         analyse_v2(N, T + R3, 18 * R3, 18)
+
+
+# ---- spectrum_f64_fused.hip: double2 elements (16 B), N = 1024, one wavefront ----
+def analyse_f64(row=68, grp=17, verbose=True):
+    """Addresses in double2 (16 B) units -> float2 units x2.  Every access is a b128."""
+    lanes = list(range(64))
+    def f2(a):       # double2 index -> float2 index
+        return 2 * a
+    w1 = sum(cycles([f2(rev16(s) * row + t) for t in lanes], W128, 4, 32) for s in range(16))
+    r1 = sum(cycles([f2((t // 4) * row + 4 * r2 + t % 4) for t in lanes], R128, 4, 64) for r2 in range(16))
+    w2 = sum(cycles([f2(rev16(s) * row + (t >> 4) * grp + (t & 15)) for t in lanes], W128, 4, 32) for s in range(16))
+    r2 = sum(cycles([f2((t // 4) * row + (t % 4) * grp + i) for t in lanes], R128, 4, 64) for i in range(16))
+    if verbose:
+        print("f64 N=1024 row=%d grp=%d: write1 %d (ideal 128) read1 %d (64) write2 %d (128) read2 %d (64)"
+              % (row, grp, w1, r1, w2, r2))
+    return w1, r1, w2, r2
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "f64":
+    analyse_f64()
+    analyse_f64(64, 16)

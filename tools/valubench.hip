@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 #define REP4(x) x x x x
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(64) void NAME(float* out, int iters, float a, float
     for (int i = 0; i < iters; ++i) {                                                  \
         asm volatile(REP16(ASM8 ASM8)                                                  \
             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)        \
-            : "v"(c));                                                                 \
+            : "v"(c), "v"(a));                                                         \
     }                                                                                  \
     out[blockIdx.x * 64 + threadIdx.x] = (float)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7); \
 }
@@ -83,6 +84,18 @@ DEF_KERNEL64(k_pkmul, I8(PKMUL))
 DEF_KERNEL64(k_pkfma, I8(PKFMA))
 DEF_KERNEL64(k_mov64, I8(MOV64))
 DEF_KERNEL64(k_lshladd64, I8(LSHLADD64))
+#define FMA64(r) "v_fma_f64 " #r ", " #r ", %8, %8\n"
+#define ADD64(r) "v_add_f64 " #r ", " #r ", %8\n"
+#define MUL64(r) "v_mul_f64 " #r ", " #r ", %8\n"
+#define FMAC64(r) "v_fmac_f64_e32 " #r ", %8, %8\n"
+#define CVT64U(r) "v_cvt_f64_u32_e32 " #r ", %9\n"
+#define CVT64F(r) "v_cvt_f64_f32_e32 " #r ", %9\n"
+DEF_KERNEL64(k_fma64, I8(FMA64))
+DEF_KERNEL64(k_add64, I8(ADD64))
+DEF_KERNEL64(k_mul64, I8(MUL64))
+DEF_KERNEL64(k_fmac64, I8(FMAC64))
+DEF_KERNEL64(k_cvt64u, I8(CVT64U))
+DEF_KERNEL64(k_cvt64f, I8(CVT64F))
 DEF_KERNEL(k_cvtub0, I16(CVT_UB0))
 DEF_KERNEL(k_cvtub1, I16(CVT_UB1))
 DEF_KERNEL(k_perm, I16(PERM))
@@ -96,6 +109,8 @@ typedef void (*kern_t)(float*, int, float, float);
 void run(const char* name, kern_t k, float* out)
 {
     printf("%-14s", name);
+    const char* only = getenv("VALUBENCH_ONLY");
+    if (only && !strstr(name, only)) return;
     for (int wps : {1, 2, 4, 8}) {
         const int blocks = 256 * 4 * wps, iters = 2000;
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -119,6 +134,8 @@ int main()
     run("fmac_e32", k_fmac, out); run("fmac_literal", k_fmac_lit, out); run("fma_vop3", k_fma_vop3, out);
     run("fma_vop3_neg", k_fma_neg, out); run("fmamk", k_fmamk, out); run("cvt_f32_i32", k_cvt, out);
     run("pk_add_f32", k_pkadd, out); run("pk_mul_f32", k_pkmul, out); run("pk_fma_f32", k_pkfma, out); run("mov_b64", k_mov64, out); run("lshl_add_u64", k_lshladd64, out);
+    run("fma_f64", k_fma64, out); run("add_f64", k_add64, out); run("mul_f64", k_mul64, out); run("fmac_f64", k_fmac64, out);
+    run("cvt_f64_u32", k_cvt64u, out); run("cvt_f64_f32", k_cvt64f, out);
     run("cvt_ubyte0", k_cvtub0, out); run("cvt_ubyte1", k_cvtub1, out); run("perm_b32", k_perm, out); run("and_or_b32", k_andor, out); run("mul_lo_u32", k_mullo, out); run("bfe_u32", k_bfe, out); run("cndmask", k_cndmask, out);
     run("add_u32", k_addu32, out); run("add_u32_sdwa", k_sdwa, out); run("mov_b32", k_mov, out);
     return 0;

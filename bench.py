@@ -137,6 +137,27 @@ def whole_job_rate(world, steps, frames_per_step, elapsed_s):
     return world * steps * frames_per_step / elapsed_s
 
 
+# ---- which device a rank uses ------------------------------------------------------
+
+def device_for_rank(local_rank, device_count):
+    """One process per GPU: rank r of the node uses device r.  A rank without a device of
+    its own is an error, never a silent share -- eight ranks on fewer devices would report
+    an 8-GPU rate that is not one."""
+    if device_count < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if not 0 <= local_rank < device_count:
+        raise SystemExit("bench.py: LOCAL_RANK %d but this host has %d HIP device(s)" % (local_rank, device_count))
+    return local_rank
+
+
+def multi_stream_plan(streams, device_count):
+    """BASELINE.json configs[4]'s placement, as rtlws_stream_device_for() states it (include/
+    rtlws_stream.h): stream i -> device i mod device_count.  Returns the device of every stream."""
+    if streams < 1 or device_count < 1:
+        raise ValueError("streams and device_count must be >= 1")
+    return [i % device_count for i in range(streams)]
+
+
 # ---- N > 1 started directly: fan out into one rank per GPU -------------------
 
 def needs_fan_out(gpus, environ):
@@ -493,6 +514,59 @@ def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
                       % (sample, frames, repsall, cores)}
 
 
+REALTIME_WORKLOAD = "realtime_8x2400k"
+
+
+def realtime_main(args):
+    """--workload realtime_8x2400k: BASELINE.json configs[4] in its real-time form -- eight paced
+    2.4 MS/s sensors (131 072-sample buffers, src/signal_source.c:29-35), stream i on device
+    i mod n_devices, host-fed over PCIe -- through rtl-ws_amd/lib/rtlws_multi_stream (C, one
+    producer thread and one rtlws_stream per sensor).  Not a roofline workload: what is
+    reported is whether every stream keeps up (drops, latency), per stream and per device."""
+    import rtlws
+    exe = os.path.join(rtlws.LIB_DIR, "rtlws_multi_stream")
+    if not os.path.exists(exe):
+        rtlws.build()
+    ndev = rtlws.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    use = min(ndev, args.gpus) if args.gpus > 1 else ndev
+    seconds = max(1.0, min(20.0, args.steps / 1000.0))
+    cmd = [exe, "--streams", "8", "--seconds", "%.2f" % seconds, "--rate", "2400000", "--output", "payload",
+           "--devices", str(use)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120 + 2 * seconds)
+    if out.returncode != 0:
+        sys.stderr.write(out.stderr)
+        return out.returncode
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    per_dev = {}
+    for st in r["per_stream"]:
+        d = per_dev.setdefault(st["device"], {"device": st["device"], "streams": [], "spectra_per_s": 0.0,
+                                              "chunks_dropped": 0, "chunks_failed": 0, "latency_ms_max": 0.0})
+        d["streams"].append(st["stream"])
+        d["spectra_per_s"] += st["spectra_per_s"]
+        d["chunks_dropped"] += st["chunks_dropped"]
+        d["chunks_failed"] += st["chunks_failed"]
+        d["latency_ms_max"] = max(d["latency_ms_max"], st["latency_ms_max"])
+    want = multi_stream_plan(8, r["devices"])
+    line = {"metric": "spectra/s (8 paced 2.4 MS/s IQ streams, 1024-pt, host-fed)", "value": r["spectra_per_s_total"],
+            "unit": "spectra/s", "n_gpus": r["devices"], "steps": args.steps, "warmup": 0,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": REALTIME_WORKLOAD, "streams": 8, "rate_hz": 2400000, "n_fft": 1024,
+                       "output": "payload_u8", "seconds": r["seconds"],
+                       "sharding": "stream i on device i mod n_devices, no collective",
+                       "real_time_rate_per_stream": 2400000 / 1024.0},
+            "roofline": None,
+            "realtime": {"chunks_dropped": r["chunks_dropped"], "chunks_failed": r["chunks_failed"],
+                         "latency_ms_avg": r["latency_ms_avg"], "latency_ms_max": r["latency_ms_max"],
+                         "stream_devices": [st["device"] for st in r["per_stream"]],
+                         "placement_as_specified": [st["device"] for st in r["per_stream"]] == want,
+                         "per_device": [per_dev[k] for k in sorted(per_dev)], "per_stream": r["per_stream"]}}
+    print(json.dumps(strict_json(line), allow_nan=False), flush=True)
+    return 0 if (r["chunks_dropped"] == 0 and r["chunks_failed"] == 0) else 5
+
+
 def plumbing_main(args):
     """--plumbing-cpu (tests only): the rank plumbing of this file with the GPU step
     replaced by a sleep -- rendezvous over gloo, barrier-bracketed timing, MAX over
@@ -500,6 +574,7 @@ def plumbing_main(args):
     import torch
     dist, world, rank = init_distributed(torch, "gloo")
     frames = WORKLOADS[args.workload][5]
+    device_for_rank(int(os.environ.get("LOCAL_RANK", "0")), max(world, 1))     # the same rule, CPU ranks
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -525,7 +600,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500,
                     help="untimed launches first; the clock governor needs ~300 (25 ms) to settle at the power cap")
-    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS) + [REALTIME_WORKLOAD])
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads on the default line")
@@ -533,6 +608,8 @@ def main(argv=None):
     ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
+    if args.workload == REALTIME_WORKLOAD:          # one process drives every device (threads, no ranks)
+        return realtime_main(args)
     if needs_fan_out(args.gpus, os.environ):
         return fan_out(args.gpus, argv, args.plumbing_cpu)
     if args.plumbing_cpu:
@@ -542,9 +619,9 @@ def main(argv=None):
     import torch
     import rtlws
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    local_rank = device_for_rank(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist, world, rank = init_distributed(torch, "nccl", device)

@@ -89,6 +89,19 @@ int rtlws_copy_d2h(rtlws_engine* e, void* dst_host, const void* src_dev, size_t 
 int rtlws_memset_dev(rtlws_engine* e, void* dst_dev, int value, size_t bytes, void* stream);
 int rtlws_stream_sync(rtlws_engine* e, void* stream);
 
+/* Additional in-order queues on the engine's device (hipStreamNonBlocking), for callers that
+ * overlap copies with kernels: rtlws_stream.h runs copy-in, transform and copy-out of
+ * consecutive chunks on three of them, ordered by events.  NULL on failure. */
+void* rtlws_queue_create(rtlws_engine* e);
+void rtlws_queue_destroy(rtlws_engine* e, void* queue);
+/* Work enqueued on `stream` after this call starts only once `ev` (recorded earlier, on any
+ * stream of the same device) has completed.  0 / -1 / -3. */
+int rtlws_queue_wait_event(rtlws_engine* e, void* stream, void* ev);
+/* An event whose rtlws_event_sync() sleeps instead of spinning (hipEventBlockingSync): for
+ * worker threads that wait on many chunks per second and should leave their core to the
+ * producers.  Not usable with rtlws_event_elapsed_ms (timing disabled). */
+void* rtlws_event_create_blocking(void);
+
 /* hipEvent timing on a stream, for bench.py's roofline leg.  A handle binds to
  * the device of the engine it is first recorded on (any thread, whatever its
  * current device is). */

@@ -49,6 +49,15 @@ typedef struct rtlws_stream_stats {
 rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
                                 int ring_slots, rtlws_stream_callback cb, void* user);
 
+/* The same with the number of in-order device queues stated: 1 <= queues <= min(ring_slots, 8).
+ * With more than one, consecutive chunks go to different queues and their copy-in, transform
+ * and copy-out overlap (a chunk's own three steps stay in order on its queue).  Worth +88 % for
+ * a device's only sensor; several sensors sharing one device do best with one queue each
+ * (rtl-ws_amd/host/stream_gpu.c has the measurements).  rtlws_stream_open() uses
+ * RTLWS_STREAM_QUEUES, default 1. */
+rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                  int ring_slots, int queues, rtlws_stream_callback cb, void* user);
+
 /* Hand over one chunk of frames_per_chunk frames of host IQ (copied before the
  * call returns).  block != 0: wait for a free ring slot; block == 0: count a
  * drop and return 1 when the ring is full.  0 on success, -1 bad argument,
@@ -61,6 +70,13 @@ int rtlws_stream_flush(rtlws_stream* s);
 void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out);
 
 void rtlws_stream_close(rtlws_stream* s);
+
+/* BASELINE.json configs[4]'s placement rule -- "GPU g <- stream g", independent streams,
+ * no collective: the device of stream `stream_index` on a host with
+ * `device_count` devices is stream_index mod device_count (8 streams on 8 devices: one
+ * each; on fewer devices they share round-robin).  -1 when either argument is invalid.
+ * Pure arithmetic: callable (and tested) without a GPU. */
+int rtlws_stream_device_for(int stream_index, int device_count);
 
 #ifdef __cplusplus
 }

@@ -440,11 +440,47 @@ int rtlws_stream_sync(rtlws_engine* e, void* stream)
 struct rtlws_event {
     hipEvent_t ev = nullptr;
     int device = -1;
+    unsigned flags = hipEventDefault;
 };
 
 void* rtlws_event_create(void)
 {
     return new rtlws_event;
+}
+
+void* rtlws_event_create_blocking(void)
+{
+    rtlws_event* x = new rtlws_event;
+    x->flags = hipEventBlockingSync | hipEventDisableTiming;
+    return x;
+}
+
+void* rtlws_queue_create(rtlws_engine* e)
+{
+    NEED_ENGINE(e, nullptr);
+    HIP_TRY(hipSetDevice(e->device), nullptr);
+    hipStream_t q = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking), nullptr);
+    return q;
+}
+
+void rtlws_queue_destroy(rtlws_engine* e, void* queue)
+{
+    if (!e || !queue || queue == RTLWS_STREAM_DEFAULT) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(queue));
+    (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(queue));
+}
+
+int rtlws_queue_wait_event(rtlws_engine* e, void* stream, void* ev)
+{
+    NEED_ENGINE(e, -1);
+    rtlws_event* x = reinterpret_cast<rtlws_event*>(ev);
+    if (!x || !x->ev) { g_err = "rtlws_queue_wait_event: event was never recorded"; return -1; }
+    if (x->device != e->device) { g_err = "rtlws_queue_wait_event: event belongs to another device"; return -1; }
+    HIP_TRY(hipSetDevice(e->device), -3);
+    HIP_TRY(hipStreamWaitEvent(pick_stream(e, stream), x->ev, 0), -3);
+    return 0;
 }
 
 void rtlws_event_destroy(void* ev)
@@ -469,7 +505,7 @@ int rtlws_event_record(void* ev, rtlws_engine* e, void* stream)
         x->ev = nullptr;
     }
     if (!x->ev) {
-        HIP_TRY(hipEventCreate(&x->ev), -3);
+        HIP_TRY(hipEventCreateWithFlags(&x->ev, x->flags), -3);
         x->device = e->device;
     }
     HIP_TRY(hipEventRecord(x->ev, pick_stream(e, stream)), -3);
@@ -490,8 +526,9 @@ float rtlws_event_elapsed_ms(void* start, void* stop)
     rtlws_event* a = reinterpret_cast<rtlws_event*>(start);
     rtlws_event* b = reinterpret_cast<rtlws_event*>(stop);
     float ms = -1.0f;
-    if (!a || !b || !a->ev || !b->ev || a->device != b->device) {
-        g_err = "rtlws_event_elapsed_ms: events must both be recorded, on the same device";
+    if (!a || !b || !a->ev || !b->ev || a->device != b->device ||
+        ((a->flags | b->flags) & hipEventDisableTiming)) {
+        g_err = "rtlws_event_elapsed_ms: events must both be recorded, on the same device, with timing";
         return -1.0f;
     }
     HIP_TRY(hipSetDevice(a->device), -1.0f);

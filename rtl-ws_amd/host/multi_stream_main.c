@@ -5,8 +5,12 @@
  * latency; unpaced mode pushes as fast as the host link allows.
  *
  *   rtlws_multi_stream [--streams S] [--seconds T] [--rate HZ | --unpaced]
- *                      [--nfft N] [--k K]
- * Prints one JSON line.
+ *                      [--nfft N] [--k K] [--output f32|db|payload]
+ *                      [--chunk-buffers M] [--queues Q] [--plan-only --devices D]
+ * Prints one JSON line: totals, and per stream its device, rate, drops and latency.
+ *   --output payload   u8 rows (the 1024 bytes src/main.c:82 sends): 4x fewer D2H bytes
+ *   --chunk-buffers M  M sensor buffers per chunk (unpaced throughput runs)
+ *   --plan-only        print the stream -> device plan for D devices and exit (no GPU needed)
  */
 #include <math.h>
 #include <pthread.h>
@@ -22,7 +26,7 @@
 struct producer {
     int id, device;
     double rate_hz, seconds;
-    int unpaced;
+    int unpaced, chunk_buffers, queues;
     rtlws_spectra_desc desc;
     rtlws_stream* st;
     rtlws_stream_stats stats;
@@ -35,7 +39,9 @@ static void on_rows(const void* rows, long nrows, long first_frame, double laten
 {
     struct producer* p = (struct producer*)user;
     (void)first_frame; (void)latency_ms;
-    p->checksum += ((const float*)rows)[0];      /* touch the data like a consumer would */
+    /* touch the data like a consumer would */
+    p->checksum += (p->desc.output == RTLWS_OUT_PAYLOAD_U8) ? (double)((const unsigned char*)rows)[0]
+                                                            : (double)((const float*)rows)[0];
     p->rows_seen += nrows;
 }
 
@@ -49,12 +55,12 @@ static double now_s(void)
 static void* producer_main(void* arg)
 {
     struct producer* p = (struct producer*)arg;
-    const long frames = BUF_SAMPLES / p->desc.n_fft;
-    unsigned char* buf = (unsigned char*)malloc(2 * BUF_SAMPLES);
+    const long frames = (long)p->chunk_buffers * (BUF_SAMPLES / p->desc.n_fft);
+    unsigned char* buf = (unsigned char*)malloc((size_t)2 * BUF_SAMPLES * (size_t)p->chunk_buffers);
     unsigned x = 2463534242u + 977u * (unsigned)p->id;
     double t0, next;
     long i;
-    for (i = 0; i < BUF_SAMPLES; i++) {      /* tone + noise, different per stream */
+    for (i = 0; i < (long)BUF_SAMPLES * p->chunk_buffers; i++) {      /* tone + noise, different per stream */
         double ph = 2.0 * 3.14159265358979 * (0.05 + 0.1 * p->id) * (double)i;
         double re, im;
         x ^= x << 13; x ^= x >> 17; x ^= x << 5;
@@ -64,14 +70,14 @@ static void* producer_main(void* arg)
         buf[2 * i] = (unsigned char)fmin(255.0, fmax(0.0, floor(re * 128.0 + 128.5)));
         buf[2 * i + 1] = (unsigned char)fmin(255.0, fmax(0.0, floor(im * 128.0 + 128.5)));
     }
-    p->st = rtlws_stream_open(p->device, &p->desc, frames, 4, on_rows, p);
+    p->st = rtlws_stream_open_q(p->device, &p->desc, frames, 4, p->queues, on_rows, p);
     if (!p->st) { fprintf(stderr, "stream %d: open failed: %s\n", p->id, rtlws_last_error()); free(buf); return NULL; }
     t0 = now_s();
     next = t0;
     while (now_s() - t0 < p->seconds) {
         if (!p->unpaced) {
             struct timespec ts;
-            next += (double)BUF_SAMPLES / p->rate_hz;
+            next += (double)BUF_SAMPLES * p->chunk_buffers / p->rate_hz;
             ts.tv_sec = (time_t)next;
             ts.tv_nsec = (long)((next - floor(next)) * 1e9);
             clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, NULL);
@@ -90,7 +96,9 @@ static void* producer_main(void* arg)
 
 int main(int argc, char** argv)
 {
-    int streams = 8, nfft = 1024, k = 1, unpaced = 0, i, ndev;
+    int streams = 8, nfft = 1024, k = 1, unpaced = 0, i, ndev, output = RTLWS_OUT_POWER_SUM;
+    int chunk_buffers = 1, plan_only = 0, devices_override = 0, queues_override = 0;
+    const char* output_name = "f32";
     double seconds = 3.0, rate = 2400000.0;
     struct producer* ps;
     pthread_t* th;
@@ -103,14 +111,41 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--nfft") && i + 1 < argc) nfft = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--k") && i + 1 < argc) k = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--unpaced")) unpaced = 1;
+        else if (!strcmp(argv[i], "--chunk-buffers") && i + 1 < argc) chunk_buffers = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--plan-only")) plan_only = 1;
+        else if (!strcmp(argv[i], "--queues") && i + 1 < argc) queues_override = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_override = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--output") && i + 1 < argc) {
+            output_name = argv[++i];
+            if (!strcmp(output_name, "f32")) output = RTLWS_OUT_POWER_SUM;
+            else if (!strcmp(output_name, "db")) output = RTLWS_OUT_MEAN_DB;
+            else if (!strcmp(output_name, "payload")) output = RTLWS_OUT_PAYLOAD_U8;
+            else { fprintf(stderr, "--output f32|db|payload\n"); return 2; }
+        }
+    }
+    if (streams < 1 || chunk_buffers < 1) { fprintf(stderr, "bad --streams / --chunk-buffers\n"); return 2; }
+    if (plan_only) {        /* the placement rule alone: no device is touched */
+        if (devices_override < 1) { fprintf(stderr, "--plan-only needs --devices D\n"); return 2; }
+        printf("{\"streams\": %d, \"devices\": %d, \"plan_only\": true, \"stream_devices\": [", streams, devices_override);
+        for (i = 0; i < streams; i++) printf("%s%d", i ? ", " : "", rtlws_stream_device_for(i, devices_override));
+        printf("]}\n");
+        return 0;
     }
     ndev = rtlws_device_count();
     if (ndev < 1) { fprintf(stderr, "no HIP device (there is no CPU path)\n"); return 2; }
+    if (devices_override > 0 && devices_override < ndev) ndev = devices_override;    /* use fewer than there are */
     ps = (struct producer*)calloc((size_t)streams, sizeof(*ps));
     th = (pthread_t*)calloc((size_t)streams, sizeof(*th));
     for (i = 0; i < streams; i++) {
         ps[i].id = i;
-        ps[i].device = i % ndev;
+        ps[i].device = rtlws_stream_device_for(i, ndev);
+        ps[i].chunk_buffers = chunk_buffers;
+        /* a device's only sensor gets four queues (consecutive chunks overlap), two sensors two
+         * each, more than that one each (stream_gpu.c); --queues overrides */
+        {
+            const int on_dev = (streams - ps[i].device + ndev - 1) / ndev;     /* sensors on this device */
+            ps[i].queues = queues_override > 0 ? queues_override : (on_dev >= 4 ? 1 : 4 / on_dev);
+        }
         ps[i].rate_hz = rate;
         ps[i].seconds = seconds;
         ps[i].unpaced = unpaced;
@@ -118,7 +153,7 @@ int main(int argc, char** argv)
         ps[i].desc.k_avg = k;
         ps[i].desc.input = RTLWS_IN_CU8;
         ps[i].desc.window = RTLWS_WIN_RECT;
-        ps[i].desc.output = RTLWS_OUT_POWER_SUM;
+        ps[i].desc.output = output;
         pthread_create(&th[i], NULL, producer_main, &ps[i]);
     }
     for (i = 0; i < streams; i++) pthread_join(th[i], NULL);
@@ -131,10 +166,19 @@ int main(int argc, char** argv)
         if (ps[i].stats.latency_ms_max > lat_max) lat_max = ps[i].stats.latency_ms_max;
     }
     printf("{\"streams\": %d, \"devices\": %d, \"paced\": %s, \"rate_hz\": %.0f, \"n_fft\": %d, \"k_avg\": %d, "
+           "\"output\": \"%s\", \"chunk_buffers\": %d, "
            "\"seconds\": %.2f, \"spectra_per_s_total\": %.1f, \"spectra_per_s_per_stream\": %.1f, "
-           "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}\n",
-           streams, ndev, unpaced ? "false" : "true", rate, nfft, k, seconds, total_rate,
+           "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f, "
+           "\"per_stream\": [",
+           streams, ndev, unpaced ? "false" : "true", rate, nfft, k, output_name, chunk_buffers, seconds, total_rate,
            total_rate / streams, frames, drops, failed, lat_avg, lat_max);
+    for (i = 0; i < streams; i++)
+        printf("%s{\"stream\": %d, \"device\": %d, \"queues\": %d, \"spectra_per_s\": %.1f, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, "
+               "\"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}", i ? ", " : "", i, ps[i].device, ps[i].queues,
+               ps[i].elapsed_s > 0 ? (double)ps[i].stats.frames_done / ps[i].elapsed_s : 0.0,
+               ps[i].stats.chunks_dropped, ps[i].stats.chunks_failed, ps[i].stats.latency_ms_avg,
+               ps[i].stats.latency_ms_max);
+    printf("]}\n");
     free(ps);
     free(th);
     return 0;

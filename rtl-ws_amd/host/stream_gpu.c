@@ -1,6 +1,24 @@
 /* stream_gpu.c -- rtlws_stream.h: pinned ring -> async H2D -> fused kernel ->
  * async D2H, several chunks in flight, in-order completion on a worker thread.
- * Plain C over include/rtlws_hip.h. */
+ * Plain C over include/rtlws_hip.h.
+ *
+ * A chunk's copy-in, transform and copy-out stay in program order on ONE in-order queue;
+ * a stream opened with Q > 1 queues sends consecutive chunks to different queues, so they
+ * overlap: chunk n+1's H2D copy runs under chunk n's kernel and chunk n-1's D2H copy (the
+ * sensor buffers of reference src/signal_source.c:29-35 keep arriving while earlier ones are
+ * still being transformed and returned).  No event chains between queues: the HIP calls per
+ * chunk stay at four (copy, launch, copy, record).  Results are delivered in push order
+ * whatever order the queues finish in (the worker walks the ring).
+ *
+ * How many queues (measured, one MI355X, 128-frame chunks, profiles/r03_multi_stream.jsonl):
+ *   one sensor on the device      1 queue 2.5e6 spectra/s, 4 queues 4.7e6 (+88 %)
+ *   four / eight sensors          1 queue EACH 6.9e6 / 5.9e6; 4 each 5.5e6 / 3.8e6 (32 HIP
+ *                                 streams oversubscribe the hardware queues); a shared pool of
+ *                                 4 or 8 queues 4.3-5.3e6; copy-in / transform / copy-out
+ *                                 queues chained by events (8 HIP calls per chunk) 3.7e6 / 2.3e6
+ * so the count is the caller's: rtlws_stream_open() takes RTLWS_STREAM_QUEUES (default 1),
+ * rtlws_stream_open_q() an argument -- the configs[4] driver gives a device's only sensor
+ * four queues and sensors that share a device one each. */
 #include "rtlws_stream.h"
 
 #include <pthread.h>
@@ -16,7 +34,8 @@ struct slot {
     void* h_out;     /* pinned */
     void* d_in;
     void* d_out;
-    void* done;      /* event recorded after the D2H copy */
+    void* q;         /* this slot's in-order queue (NULL: the engine's own) */
+    void* done;      /* recorded after the D2H copy; the worker sleeps on it */
     int state;
     long first_frame;
     double t_push_ms;
@@ -24,6 +43,8 @@ struct slot {
 
 struct rtlws_stream {
     rtlws_engine* eng;
+    int nq;                          /* dedicated queues of this stream (0: the engine's own) */
+    void* q[8];
     rtlws_spectra_desc desc;
     long frames_per_chunk, rows_per_chunk;
     size_t in_bytes, out_bytes;
@@ -40,6 +61,12 @@ struct rtlws_stream {
     rtlws_stream_stats st;
     double lat_sum;
 };
+
+int rtlws_stream_device_for(int stream_index, int device_count)
+{
+    if (stream_index < 0 || device_count < 1) return -1;
+    return stream_index % device_count;
+}
 
 static double now_ms(void)
 {
@@ -101,10 +128,21 @@ static void* worker_main(void* arg)
 rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
                                 int ring_slots, rtlws_stream_callback cb, void* user)
 {
+    const char* q = getenv("RTLWS_STREAM_QUEUES");
+    int queues = q ? atoi(q) : 1;
+    if (queues < 1) queues = 1;
+    if (queues > ring_slots) queues = ring_slots;
+    if (queues > 8) queues = 8;
+    return rtlws_stream_open_q(device, desc, frames_per_chunk, ring_slots, queues, cb, user);
+}
+
+rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                  int ring_slots, int queues, rtlws_stream_callback cb, void* user)
+{
     rtlws_stream* s;
     int i;
     if (!desc || rtlws_spectra_kernel_kind(desc) == 0 || frames_per_chunk <= 0 ||
-        frames_per_chunk % desc->k_avg || ring_slots < 2)
+        frames_per_chunk % desc->k_avg || ring_slots < 2 || queues < 1 || queues > 8 || queues > ring_slots)
         return NULL;
     s = (rtlws_stream*)calloc(1, sizeof(*s));
     if (!s) return NULL;
@@ -123,13 +161,23 @@ rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long
     pthread_mutex_init(&s->mu, NULL);
     pthread_cond_init(&s->cv_work, NULL);
     pthread_cond_init(&s->cv_free, NULL);
+    if (queues > 1) {                 /* 1: the engine's own queue, as before */
+        for (i = 0; i < queues; i++) {
+            s->q[i] = rtlws_queue_create(s->eng);
+            if (!s->q[i]) { rtlws_stream_close(s); return NULL; }
+            s->nq = i + 1;
+        }
+    }
     for (i = 0; i < ring_slots; i++) {
         struct slot* sl = &s->slots[i];
+        sl->q = s->nq ? s->q[i % s->nq] : NULL;
         sl->h_in = rtlws_pinned_alloc(s->in_bytes);
         sl->h_out = rtlws_pinned_alloc(s->out_bytes);
         sl->d_in = rtlws_dev_alloc(s->eng, s->in_bytes);
         sl->d_out = rtlws_dev_alloc(s->eng, s->out_bytes);
-        sl->done = rtlws_event_create();
+        /* the worker sleeps on the event, it does not spin (RTLWS_STREAM_SPIN=1: it spins; A/B) */
+        sl->done = (getenv("RTLWS_STREAM_SPIN") && getenv("RTLWS_STREAM_SPIN")[0] == '1') ? rtlws_event_create()
+                                                                                            : rtlws_event_create_blocking();
         if (!sl->h_in || !sl->h_out || !sl->d_in || !sl->d_out || !sl->done) {
             rtlws_stream_close(s);
             return NULL;
@@ -161,15 +209,15 @@ int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block)
     sl->first_frame = s->next_frame;
     sl->t_push_ms = now_ms();
     memcpy(sl->h_in, iq_host, s->in_bytes);
-    /* one in-order queue per sensor: copy in, transform, copy out, mark */
-    if (rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, NULL) ||
-        rtlws_spectra_batch(s->eng, &s->desc, sl->d_in, s->frames_per_chunk, sl->d_out, NULL) ||
-        rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, NULL) ||
-        rtlws_event_record(sl->done, s->eng, NULL)) {
+    /* copy in, transform, copy out, mark: in program order on this slot's queue */
+    if (rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, sl->q) ||
+        rtlws_spectra_batch(s->eng, &s->desc, sl->d_in, s->frames_per_chunk, sl->d_out, sl->q) ||
+        rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, sl->q) ||
+        rtlws_event_record(sl->done, s->eng, sl->q)) {
         /* part of the chain may already be queued against this slot's buffers, and
          * the slot stays FREE: drain the queue so that the next push cannot
          * overwrite h_in / d_in under a copy or a kernel still in flight */
-        rtlws_stream_sync(s->eng, NULL);
+        rtlws_stream_sync(s->eng, sl->q);
         s->st.chunks_failed++;
         s->next_frame += s->frames_per_chunk;          /* the lost frames keep their numbers */
         rc = -3;
@@ -227,6 +275,7 @@ void rtlws_stream_close(rtlws_stream* s)
         rtlws_event_destroy(sl->done);
     }
     free(s->slots);
+    for (i = 0; i < s->nq; i++) rtlws_queue_destroy(s->eng, s->q[i]);
     rtlws_engine_destroy(s->eng);
     pthread_mutex_destroy(&s->mu);
     pthread_cond_destroy(&s->cv_work);

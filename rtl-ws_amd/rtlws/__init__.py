@@ -66,11 +66,12 @@ HIP_SYMBOLS = [
     "rtlws_cic_block_sums", "rtlws_halfband", "rtlws_spectra_grid", "rtlws_payload_from_sums",
     "rtlws_fm_demod", "rtlws_copy_d2d", "rtlws_spectra_batch_f64", "rtlws_payload_from_sums_f64",
     "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64",
+    "rtlws_queue_create", "rtlws_queue_destroy", "rtlws_queue_wait_event", "rtlws_event_create_blocking",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
-STREAM_SYMBOLS = ["rtlws_stream_open", "rtlws_stream_push", "rtlws_stream_flush",
-                  "rtlws_stream_get_stats", "rtlws_stream_close"]
+STREAM_SYMBOLS = ["rtlws_stream_open", "rtlws_stream_open_q", "rtlws_stream_push", "rtlws_stream_flush",
+                  "rtlws_stream_get_stats", "rtlws_stream_close", "rtlws_stream_device_for"]
 AMD_SYMBOLS = [
     "spectrum_alloc", "spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32",
     "spectrum_free", "cic_decimate", "halfband_decimate", "rf_decimator_alloc",
@@ -131,6 +132,11 @@ def hip_lib():
         L.rtlws_memset_dev.argtypes = [vp, vp, i, sz, vp]
         L.rtlws_stream_sync.argtypes = [vp, vp]
         L.rtlws_event_create.restype = vp
+        L.rtlws_event_create_blocking.restype = vp
+        L.rtlws_queue_create.argtypes = [vp]
+        L.rtlws_queue_create.restype = vp
+        L.rtlws_queue_destroy.argtypes = [vp, vp]
+        L.rtlws_queue_wait_event.argtypes = [vp, vp, vp]
         L.rtlws_event_destroy.argtypes = [vp]
         L.rtlws_event_record.argtypes = [vp, vp, vp]
         L.rtlws_event_elapsed_ms.argtypes = [vp, vp]

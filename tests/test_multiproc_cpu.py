@@ -8,6 +8,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
@@ -25,10 +27,12 @@ WORKER = textwrap.dedent("""
     dist.barrier()
     elapsed = time.perf_counter() - t0
     mine = elapsed
+    own = [0.011, 0.033][rank]                 # what a rank would time around its own launches
     elapsed, other = bench.max_over_ranks(torch, dist, [elapsed, float(rank)])
+    per_rank = bench.gather_ranks(torch, dist, own)
     if rank == 0:
         print(json.dumps({"value": bench.whole_job_rate(world, steps, frames, elapsed),
-                          "elapsed": elapsed, "max_rank": other, "world": world}))
+                          "elapsed": elapsed, "max_rank": other, "world": world, "per_rank": per_rank}))
     dist.barrier()
     dist.destroy_process_group()
 """) % ROOT
@@ -48,6 +52,7 @@ def test_two_rank_gloo_timing_and_aggregation(tmp_path):
         assert p.returncode == 0, err[-2000:]
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["world"] == 2 and res["max_rank"] == 1.0
+    assert res["per_rank"] == [0.011, 0.033]        # every rank's own figure, in rank order (bench line: per_rank)
     # both ranks are bracketed by barriers, so the job lasts as long as the slow rank
     assert 0.19 < res["elapsed"] < 1.0
     assert abs(res["value"] - 2 * 5 * 1000 / res["elapsed"]) < 1e-6
@@ -103,3 +108,31 @@ def test_fan_out_decision():
     assert bench.needs_fan_out(2, {}) and bench.needs_fan_out(8, {"HOME": "/"})
     assert not bench.needs_fan_out(1, {})
     assert not bench.needs_fan_out(2, {"WORLD_SIZE": "2", "RANK": "0"})     # already a rank
+
+
+def test_rank_and_stream_placement_for_1_2_8_devices():
+    """VERDICT r2 "next" #5: the rank -> device and stream -> device rules as functions, checked
+    for device counts this container cannot have.  bench.py's rule and the C driver's
+    (rtlws_stream_device_for, include/rtlws_stream.h; rtlws_multi_stream --plan-only) must agree."""
+    import ctypes
+    import json
+    import subprocess
+    import bench
+    import rtlws
+    L = rtlws.amd_lib()
+    L.rtlws_stream_device_for.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.rtlws_stream_device_for.restype = ctypes.c_int
+    exe = os.path.join(rtlws.LIB_DIR, "rtlws_multi_stream")
+    for n in (1, 2, 8):
+        plan = bench.multi_stream_plan(8, n)
+        assert plan == [i % n for i in range(8)]
+        assert [L.rtlws_stream_device_for(i, n) for i in range(8)] == plan
+        out = subprocess.run([exe, "--plan-only", "--devices", str(n)], capture_output=True, text=True, timeout=30)
+        assert out.returncode == 0 and json.loads(out.stdout)["stream_devices"] == plan
+        assert [bench.device_for_rank(r, n) for r in range(n)] == list(range(n))      # one rank, one device
+        with pytest.raises(SystemExit):
+            bench.device_for_rank(n, n)                                              # no silent sharing
+    assert bench.multi_stream_plan(8, 8) == list(range(8))                           # configs[4]: GPU g <- stream g
+    assert L.rtlws_stream_device_for(3, 0) == -1 and L.rtlws_stream_device_for(-1, 8) == -1
+    with pytest.raises(SystemExit):
+        bench.device_for_rank(0, 0)

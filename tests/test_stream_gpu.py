@@ -104,6 +104,64 @@ def test_multi_stream_driver_realtime_no_drops(built):
     assert out.returncode == 0, out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["streams"] == 8 and r["chunks_dropped"] == 0 and r["chunks_failed"] == 0
+    # the placement rule (stream i -> device i mod n_devices), stated per stream in the line
+    assert r["devices"] == built.device_count() >= 1
+    assert [s["device"] for s in r["per_stream"]] == [i % r["devices"] for i in range(8)]
+    assert all(s["chunks_dropped"] == 0 and 0.9 * 2343.75 < s["spectra_per_s"] < 1.1 * 2343.75 for s in r["per_stream"])
     # 2.4 MS/s / 1024 = 2343.75 spectra/s per stream
     assert 0.9 * 2343.75 < r["spectra_per_s_per_stream"] < 1.1 * 2343.75
     assert r["latency_ms_avg"] < 20 and r["latency_ms_max"] < 1000     # max includes the cold first launch
+
+
+def test_bench_realtime_workload_reports_per_device(built):
+    """bench.py --workload realtime_8x2400k wraps the driver: zero drops, the stream -> device
+    list as specified, one entry per device."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "realtime_8x2400k",
+                          "--steps", "1500"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    rt = r["realtime"]
+    assert rt["chunks_dropped"] == 0 and rt["placement_as_specified"] and r["roofline"] is None
+    assert len(rt["per_device"]) == r["n_gpus"] and sorted(sum((d["streams"] for d in rt["per_device"]), [])) == list(range(8))
+    assert 0.9 * 8 * 2343.75 < r["value"] < 1.1 * 8 * 2343.75
+
+
+@pytest.mark.parametrize("queues", ["3", "1"])
+def test_stream_queue_per_slot_and_one_queue_give_the_same_rows(built, oracle, queues):
+    """One in-order queue per ring slot (consecutive chunks overlap) and the one-queue form
+    deliver the same rows, in push order, for payload output as well."""
+    import ctypes as C
+    from rtlws import synth
+    os.environ["RTLWS_STREAM_QUEUES"] = queues
+    try:
+        L = built.amd_lib()
+        L.rtlws_stream_open.restype = C.c_void_p
+        L.rtlws_stream_open.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+        L.rtlws_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rtlws_stream_flush.argtypes = [C.c_void_p]
+        L.rtlws_stream_close.argtypes = [C.c_void_p]
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_long, C.c_double, C.c_void_p)
+        got = []
+
+        def cb(rows, nrows, first, lat, user):
+            got.append((first, np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_uint8)), shape=(nrows, 1024)).copy()))
+
+        cbf = CB(cb)
+        d = built.make_desc(1024, 2, "cu8", "rect", "payload_u8", 0, 15)
+        h = L.rtlws_stream_open(0, C.byref(d), 64, 3, cbf, None)
+        assert h
+        iq = synth.tone_noise_iq(64 * 12, 1024, seed=44)
+        for c in range(12):
+            assert L.rtlws_stream_push(h, iq[64 * c:64 * (c + 1)].ctypes.data_as(C.c_void_p), 1) == 0
+        L.rtlws_stream_flush(h)
+        L.rtlws_stream_close(h)
+    finally:
+        os.environ.pop("RTLWS_STREAM_QUEUES", None)
+    assert [f for f, _ in got] == [64 * c for c in range(12)]
+    rows = np.concatenate([r for _, r in got])
+    ref = oracle.batch_spectra_u8(iq, 1024, K=2, nthreads=4)
+    want = np.stack([oracle.spectrum_payload(r, 2, 15) for r in ref])
+    diff = np.abs(rows.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 5e-3       # f32 batch kernel: +-1 only next to an integer dB

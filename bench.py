@@ -81,12 +81,21 @@ def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum", f64=Fal
     return 2 * n_fft * max(cic_r, 1) + out_bytes * n_fft // k_avg
 
 
-def synth_iq_torch(torch, nframes, samples_per_frame, seed, device):
+def synth_iq_torch(torch, nframes, samples_per_frame, seed, device, kind="tone"):
     """Tone (amp 0.6, random frequency) + Gaussian noise (sigma 0.05), quantised
-    to offset-binary u8 -- SURVEY.md §8d's input, generated on the device."""
+    to offset-binary u8 -- SURVEY.md §8d's input, generated on the device.
+    kind="uniform": §8d's other variant, every byte uniform in 0..255 (the kernels are
+    data-independent: this is a parity case, the rate does not move)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = torch.empty((nframes, samples_per_frame, 2), dtype=torch.uint8, device=device)
+    if kind == "uniform":
+        step = max(1, (1 << 26) // (2 * samples_per_frame))
+        for a in range(0, nframes, step):
+            b = min(a + step, nframes)
+            out[a:b] = torch.randint(0, 256, (b - a, samples_per_frame, 2), generator=g, device=device,
+                                     dtype=torch.uint8)
+        return out
     chunk = max(1, (1 << 24) // samples_per_frame)
     n = torch.arange(samples_per_frame, device=device, dtype=torch.float32)[None, :]
     for a in range(0, nframes, chunk):
@@ -314,7 +323,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     out_cols = 2 * n_fft if cic_only else n_fft
     with torch.cuda.stream(tstream):
         outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
-        ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device) for s in range(sets)]
+        ins = [synth_iq_torch(torch, frames, spf, 1234 + 17 * s + 1000 * rank, device, ctx.get("input", "tone"))
+               for s in range(sets)]
     torch.cuda.synchronize()
     L = rtlws.hip_lib()
     launch = eng.spectra_batch_f64 if f64 else eng.spectra_batch
@@ -392,7 +402,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             "data": "synthetic",
             "config": {"workload": name, "n_fft": n_fft, "frames_per_step": frames,
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
-                       "input": "cmplx_u8 tone(0.6)+noise(0.05), device-resident, %d rotating sets" % sets,
+                       "input": "cmplx_u8 %s, device-resident, %d rotating sets"
+                                % ("uniform random bytes" if ctx.get("input") == "uniform" else "tone(0.6)+noise(0.05)", sets),
                        "sharding": "independent frames per GPU, no collective"},
             # frac      : algorithmic bytes / average launch duration between HIP events recorded on the
             #             launch stream around the timed launches (the kernel's own time)
@@ -435,11 +446,11 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     return result
 
 
-# Vector-issue utilisation of the dominant kernel: wave64 VALU instructions per launch (a
-# property of the code and the launch shape, counted once by rocprofv3 --pmc SQ_INSTS_VALU and
-# committed in profiles/valu_insts.json) x 2 issue cycles for the plain f32 instructions (the
-# conversions take 4: counted as two slots there) / the SIMD-cycles the launch lasted (4 SIMDs per
-# CU x CUs x launch time x the shader clock under load, committed beside the count).
+# Vector-issue utilisation of the dominant kernel: the issue cycles one launch needs on a SIMD
+# (wave64 VALU instructions per launch, counted by rocprofv3 --pmc SQ_INSTS_VALU, x 2 cycles -- 4 for
+# conversions, SDWA and every f64 instruction; tools/make_valu_insts.py, profiles/valu_insts.json) /
+# the SIMD-cycles this run's launch lasted (4 SIMDs per CU x CUs x launch time x the shader clock
+# rocm-smi showed under sustained load of the same workload, committed beside the count).
 def valu_issue_frac(name, avg_launch_s, cu_count):
     path = os.path.join(ROOT, "profiles", "valu_insts.json")
     try:
@@ -449,9 +460,9 @@ def valu_issue_frac(name, avg_launch_s, cu_count):
     if not rec:
         return None
     simd_cycles = 4 * cu_count * avg_launch_s * rec["sclk_ghz_under_load"] * 1e9
-    return {"valu_issue_frac": rec["issue_slots_per_launch"] * 2.0 / simd_cycles,
-            "valu_issue_source": "profiles/valu_insts.json (SQ_INSTS_VALU per launch and sclk under load, "
-                                 "committed) x this run's launch duration"}
+    return {"valu_issue_frac": rec["issue_cycles_per_launch"] / simd_cycles,
+            "valu_issue_source": "profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost, sclk under "
+                                 "load: committed measurements) / this run's launch duration"}
 
 
 def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
@@ -602,6 +613,8 @@ def main(argv=None):
                     help="untimed launches first; the clock governor needs ~300 (25 ms) to settle at the power cap")
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS) + [REALTIME_WORKLOAD])
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
+    ap.add_argument("--input", default="tone", choices=["tone", "uniform"],
+                    help="synthetic IQ: tone + noise (SURVEY.md 8d, default) or uniform random bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads on the default line")
     ap.add_argument("--frames", type=int, default=0, help="override frames per step (experiments)")
@@ -632,6 +645,7 @@ def main(argv=None):
     ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
            "rank": rank, "device": device,
            # ONE side stream carries input synthesis and every launch (run_workload, "Stream order")
+           "input": args.input,
            "stream": torch.cuda.Stream(device=device),
            "cu_count": torch.cuda.get_device_properties(device).multi_processor_count}
 

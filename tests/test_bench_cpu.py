@@ -113,9 +113,9 @@ def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
     import bench
     (tmp_path / "profiles").mkdir()
     (tmp_path / "profiles" / "valu_insts.json").write_text(json.dumps(
-        {"w": {"issue_slots_per_launch": 4.0e7, "sclk_ghz_under_load": 2.0}}))
+        {"w": {"issue_cycles_per_launch": 8.0e7, "sclk_ghz_under_load": 2.0}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     out = bench.valu_issue_frac("w", 80e-6, 256)
-    # 4e7 slots x 2 cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
+    # 8e7 issue cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
     assert abs(out["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.0e9)) < 1e-12
     assert bench.valu_issue_frac("other", 80e-6, 256) is None

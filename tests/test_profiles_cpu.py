@@ -30,7 +30,21 @@ def test_hbm_traffic_is_close_to_algorithmic():
     sys.path.insert(0, ROOT)
     import bench
     t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-    for name in ("batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic12_2048pt"):
+    for name in ("batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic12_2048pt", "cic8_2048pt",
+                 "batched_1024pt_64k_frames_f64"):
         n_fft, k_avg, window, output, cic_r, frames = bench.WORKLOADS[name]
-        alg = bench.algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output) * frames
+        alg = bench.algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, name in bench.F64_WORKLOADS) * frames
         assert 0.97 <= t[name]["bytes_per_launch"] / alg <= 1.03, (name, t[name]["bytes_per_launch"], alg)
+
+
+def test_valu_issue_fractions_are_plausible():
+    """profiles/valu_insts.json x the committed launch durations: between a third and two thirds of
+    the SIMDs' issue cycles on the f32 FFT kernels (none of them is issue-bound)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for name, lo, hi in (("hann_4096pt_k8_db", 0.45, 0.65), ("batched_1024pt_64k_frames", 0.40, 0.60),
+                         ("batched_1024pt_64k_frames_f64", 0.30, 0.60)):
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_%s_timed_launches.json" % name)))
+        v = bench.valu_issue_frac(name, t["timed_avg_ns"] * 1e-9, 256)
+        assert v is not None and lo < v["valu_issue_frac"] < hi, (name, v)

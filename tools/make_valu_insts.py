@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""profiles/valu_insts.json -- what bench.py's roofline.valu_issue_frac is computed from.
+
+For a workload: the vector-issue cycles one launch needs on a SIMD,
+    issue_cycles_per_launch = sum over instruction classes of (wave64 instructions x issue cycles),
+from rocprofv3's SQ_INSTS_VALU per launch (profiles/r03_<workload>_pmc.json) split by class with
+the kernel's own ISA (hipcc -S; tools/isa_hist.py): plain f32 / integer VALU 2 cycles, conversions
+and SDWA 4, every f64 instruction 4 (tools/valubench.hip, measured on gfx950) -- and the shader
+clock rocm-smi showed under sustained load of that workload (profiles/r03_power_clocks.txt).
+bench.py divides by the SIMD-cycles its own launch lasted: 4 SIMDs x CUs x launch time x sclk.
+
+usage: make_valu_insts.py profiles/valu_insts.json
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(workload):
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)))["counters"]
+
+
+def entry(workload, frames, four_cycle_per_frame, sclk_ghz, note):
+    """four_cycle_per_frame: wave64 instructions per frame that issue in 4 cycles instead of 2."""
+    insts = pmc(workload)["SQ_INSTS_VALU"]["mean_per_launch"]
+    four = four_cycle_per_frame * frames
+    cycles = 2.0 * (insts - four) + 4.0 * four
+    return {"sq_insts_valu_per_launch": insts, "four_cycle_insts_per_launch": four,
+            "issue_cycles_per_launch": cycles, "sclk_ghz_under_load": sclk_ghz, "frames_per_launch": frames,
+            "note": note}
+
+
+def main():
+    out = {
+        # 4 wavefronts x 32 v_cvt_f32_ubyteN per frame
+        "hann_4096pt_k8_db": entry("hann_4096pt_k8_db", 16384, 128, 2.198,
+                                   "spectra_fused<4096, u8, Hann, dB, K>1>: 128 byte conversions per frame at 4 cycles; "
+                                   "sclk 2.194-2.202 GHz at 1 354-1 372 W (profiles/r03_power_clocks.txt)"),
+        # 1 wavefront x 32 conversions per frame
+        "batched_1024pt_64k_frames": entry("batched_1024pt_64k_frames", 65536, 32, 1.886,
+                                           "spectra_fused<1024, u8, rect, sum, K=1>: 32 byte conversions per frame at 4 "
+                                           "cycles; sclk 1.884-1.892 GHz at 1 394-1 402 W (the cap)"),
+        # per frame (one wavefront): 386 f64 arithmetic + 32 conversions to f64 + 32 SDWA integer adds at 4 cycles
+        "batched_1024pt_64k_frames_f64": entry("batched_1024pt_64k_frames_f64", 65536, 386 + 32 + 32, 2.03,
+                                               "spectra_f64_fused<rect, sum, K=1>: 386 f64 add / mul / fma, 32 "
+                                               "v_cvt_f64_*, 32 SDWA integer adds per frame at 4 cycles; sclk "
+                                               "2.02-2.05 GHz at 1 375-1 382 W"),
+    }
+    json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
+    for k, v in out.items():
+        print(k, "%.4g issue cycles per launch" % v["issue_cycles_per_launch"])
+
+
+if __name__ == "__main__":
+    main()

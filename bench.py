@@ -66,8 +66,12 @@ WORKLOADS = {
     # the reference's own precision on batches (src/spectrum.c:54-60,28 is f64 end to end):
     # rtlws_spectra_batch_f64, rows of doubles out -- 2N + 8N/K = 10 240 B per spectrum
     "batched_1024pt_64k_frames_f64": (1024, 1, "rect", "power_sum", 0, 65536),
+    # configs[2] in f64 (2*4096 + 8*4096/8 = 12 288 B per frame), and the other two fused sizes
+    "hann_4096pt_k8_db_f64": (4096, 8, "hann", "mean_db", 0, 16384),
+    "rect_2048pt_f64": (2048, 1, "rect", "power_sum", 0, 32768),
+    "rect_4096pt_f64": (4096, 1, "rect", "power_sum", 0, 16384),
 }
-F64_WORKLOADS = ("batched_1024pt_64k_frames_f64",)
+F64_WORKLOADS = ("batched_1024pt_64k_frames_f64", "hann_4096pt_k8_db_f64", "rect_2048pt_f64", "rect_4096pt_f64")
 HEADLINE = "batched_1024pt_64k_frames"
 # configs[2], configs[3] and the reference's own decimation factor ride along on the default line
 EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", "batched_1024pt_64k_frames_f64")
@@ -258,7 +262,7 @@ def parity_block(np, po, wl, host_in, got, nchk):
 # kernel's budget, DESIGN.md §5: the same bounds tests/ assert)
 PARITY_BOUNDS = {"max_rel_err_floor1e-5": 1e-4, "max_rel_err_floor1e-9": 5e-3, "p99.9_rel_err_floor1e-9": 1e-4,
                  "max_abs_db_err": 2e-4, "max_byte_diff": 1}
-PARITY_BOUNDS_F64 = {"max_rel_err_floor1e-9": 1e-10}
+PARITY_BOUNDS_F64 = {"max_rel_err_floor1e-9": 1e-10, "max_abs_db_err": 1e-9}
 
 
 def parity_failures(block, bounds=None):

@@ -94,10 +94,17 @@ struct SpectraParamsF64 {
 };
 
 // which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip)
-constexpr bool f64_fused_kind(int n_fft, int in_kind, int cic_r) { return n_fft == 1024 && in_kind == IN_CU8 && cic_r <= 1; }
-constexpr int f64_fused_lds_bytes() { return 16 * 68 * 16; }          // 16 padded rows of double2
-constexpr int f64_fused_blocks_per_cu() { return 8; }                  // 2 one-wavefront workgroups per SIMD
-hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int blocks, hipStream_t);
+constexpr bool f64_fused_kind(int n_fft, int in_kind, int cic_r)
+{
+    return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && in_kind == IN_CU8 && cic_r <= 1;
+}
+// LDS in double2 elements: 16 rows of 17*R3 (the larger of the two transpositions ends at
+// 15*17*R3 + (R3-1)*17 + 16) + one element for the DC slot of the multi-wavefront sizes
+constexpr int f64_fused_lds_elems(int n_fft) { return 15 * 17 * (n_fft / 256) + (n_fft / 256 - 1) * 17 + 16 + 1; }
+constexpr int f64_fused_lds_bytes(int n_fft) { return 16 * f64_fused_lds_elems(n_fft); }
+// 8 wavefronts per CU (2 per SIMD) at every size: 8 / 4 / 2 workgroups
+constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
+hipError_t launch_spectra_f64_fused(const SpectraParamsF64&, int blocks, hipStream_t);
 
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
 // second argument), by instantiation, chosen so that NO instantiation spills

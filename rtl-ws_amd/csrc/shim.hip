@@ -215,7 +215,7 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
         free_tables(tb);
         return -3;
     }
-    if (n_fft == 1024) {
+    if (is_fused_n(n_fft)) {
         // the fused f64 kernel's tables: the f32 kernel's (get_tables), evaluated in long double
         // and rounded once to double; the u8 input scale 1/128 folded into tw1 (exact)
         const int T = n_fft / 16, R3 = n_fft / 256, NP = R3 / 2;
@@ -716,14 +716,14 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     const char* ff = getenv("RTLWS_F64_FUSED");
     if (rtlws::f64_fused_kind(d->n_fft, d->input, d->cic_r) && !(ff && ff[0] == '0') &&
         !(reinterpret_cast<uintptr_t>(d_out) & 15u)) {
-        int per_cu = rtlws::f64_fused_blocks_per_cu();
+        int per_cu = rtlws::f64_fused_blocks_per_cu(d->n_fft);
         if (const char* ov = getenv("RTLWS_F64_BLOCKS_PER_CU")) {   // experiments only
             const int v = atoi(ov);
-            if (v > 0 && v <= 9) per_cu = v;
+            if (v > 0 && v <= per_cu + 1) per_cu = v;
         }
         long blocks = (long)e->cu_count * per_cu;
         if (blocks > p.ngroups) blocks = p.ngroups;
-        err = rtlws::launch_spectra_f64_fused_1024(p, (int)blocks, pick_stream(e, stream));
+        err = rtlws::launch_spectra_f64_fused(p, (int)blocks, pick_stream(e, stream));
     } else {
         err = rtlws::launch_spectra_f64(p, d->input, pick_stream(e, stream));
     }

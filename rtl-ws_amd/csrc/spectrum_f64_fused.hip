@@ -1,29 +1,32 @@
-// spectrum_f64_fused.hip -- 1024-point cmplx_u8 frames -> power spectra in DOUBLE, at
-// throughput: the batch form of what the reference computes per frame (src/spectrum.c:54-60
+// spectrum_f64_fused.hip -- 1024- / 2048- / 4096-point cmplx_u8 frames -> power spectra in
+// DOUBLE, at throughput: the batch form of what the reference computes per frame (src/spectrum.c:54-60
 // convert to double, :21 f64 forward DFT, :23-34 |X|^2 + fft-shift + accumulate + DC-slot
 // rule into a double buffer; K loop of src/cbb_main.c:50-59; dB / truncate / clamp of
 // src/cbb_main.c:121-130 in double, same operation order).
 //
 // The f32 fused kernel holds "<= 1e-4 relative" only against a floor 50 dB under a row's
 // maximum (f32 rounding next to a strong tone); the reference is f64 end to
-// end.  This kernel is the same radix-16 x 16 x 4 structure as spectrum_fused.hip at
-// N = 1024 -- one 64-lane wavefront per frame, sixteen complex points per lane, two
-// wave-private LDS transpositions, no barrier -- with every value a double: strict-metric
-// error (floor 1e-9 of the row maximum) ~1e-13, i.e. rtlws_spectra_batch_f64 at batch
-// rates instead of one workgroup-per-row radix-2 (spectrum_f64.hip, which keeps every
-// other N, the cmplx_s32 / real-f32 inputs and the CIC-fused form).
+// end.  This kernel is the same radix-16 x 16 x R3 structure as spectrum_fused.hip (R3 =
+// N/256; N/16 threads per frame -- one 64-lane wavefront at N = 1024, where nothing needs a
+// barrier, two at 2048, four at 4096 -- sixteen complex points per lane, two LDS
+// transpositions) with every value a double: strict-metric error (floor 1e-9 of the row
+// maximum) ~1e-12, i.e. rtlws_spectra_batch_f64 at batch rates instead of one
+// workgroup-per-row radix-2 (spectrum_f64.hip, which keeps every other N, the cmplx_s32 /
+// real-f32 inputs and the CIC-fused form).
 //
 // Cost model (MI355X): v_fma_f64 / v_add_f64 / v_mul_f64 issue at 4 cycles per wave64
 // instruction -- half the f32 rate, and the rate ONE wavefront can issue at by itself, so 2
 // wavefronts per SIMD are enough; ~560 of them per frame = 560 CU-cycles at 4 SIMDs.
 // Algorithmic bytes: 2N in + 8N/K out = 10 240 B per spectrum at K = 1.
 //
-// LDS (double2 units, one buffer reused by both transpositions; tools/lds_sim.py f64):
-//   transposition 1  (q1, m1) at q1*68 + m1: rows of 64 padded to 68, so that the pass-2
-//       ds_read_b128 groups ({0-3,12-15,20-27}: rows 0,3,5,6 / {4-11,16-19,28-31}: rows
-//       1,2,4,7) land on four different 64-byte bank quarters;
-//   transposition 2  (q1, m2, q2) at q2*68 + (q1/4)*17 + (q1%4)*4 + m2: a reader lane's
+// LDS (double2 units, one buffer reused by both transpositions; tools/lds_sim.py f64;
+// ROW = 17*R3 = 68 / 136 / 272):
+//   transposition 1  (q1, m1) at q1*ROW + m1: rows of T padded to ROW, so that the pass-2
+//       ds_read_b128 lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) land on
+//       different 64-byte bank quarters;
+//   transposition 2  (q1, m2, q2) at q2*ROW + (q1/J)*17 + (q1%J)*R3 + m2: a reader lane's
 //       sixteen elements are contiguous, groups of 16 padded to 17.
+// Every ds_write_b128 / ds_read_b128 of both is conflict-free at all three sizes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,13 +37,11 @@ namespace rtlws {
 
 using namespace f64;      // f2 = double2, real = double, fft16_fma, fft_last, hann_w ... in double
 
-constexpr int F64F_N = 1024, F64F_T = 64, F64F_R3 = 4, F64F_J = 4;
-constexpr int F64F_ROW = 68;
-
-template <bool WIN, int OUT, bool KONE>
-__global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF64 p)
+template <int N, bool WIN, int OUT, bool KONE>
+__global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraParamsF64 p)
 {
-    constexpr int N = F64F_N, T = F64F_T, R3 = F64F_R3, J = F64F_J;
+    constexpr int T = N / 16, R3 = N / 256, J = 16 / R3;
+    constexpr int F64F_ROW = 17 * R3;
     extern __shared__ __attribute__((aligned(16))) double2 ldsd[];
 
     const int t = threadIdx.x;
@@ -61,15 +62,19 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
     };
     if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
 
+    // the last pass's (cos, tan) pairs stay in registers, except in the one instantiation whose
+    // budget they break (4096-point, window, K-frame accumulators: 32 VGPRs of pairs): there
+    // they are re-read from the (L2-resident, 2 KiB) table every frame, under the LDS reads
+    constexpr bool TW3_REGS = !(N == 4096 && WIN && !KONE);
     f2 tw1[16], tw3[R3 / 2];
 #pragma unroll
     for (int s = 0; s < 16; ++s) tw1[s] = p.tw1f[t * 16 + s];
 #pragma unroll
-    for (int m = 0; m < R3 / 2; ++m) tw3[m] = p.tw2f[(t / R3) * (R3 / 2) + m];
+    for (int m = 0; m < R3 / 2; ++m) tw3[m] = TW3_REGS ? p.tw2f[(t / R3) * (R3 / 2) + m] : mk(0.0, 0.0);
     // Hann weights from two lane constants (fft_regs_impl.h): sixteen registers pairs for K = 1;
     // with K-frame accumulators beside them the 256-VGPR budget is 2 short, so that form
     // regenerates them every frame (two FMAs each)
-    constexpr bool WINREGS = WIN && KONE;
+    constexpr bool WINREGS = WIN && KONE && N == 1024;
     f2 wcs = WIN ? p.hann_csf[t] : mk(0.0, 0.0);
     double win[16];
 #pragma unroll
@@ -80,8 +85,10 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(win[r]));
     }
+    if constexpr (TW3_REGS) {
 #pragma unroll
-    for (int m = 0; m < R3 / 2; ++m) asm volatile("" ::"v"(tw3[m].x), "v"(tw3[m].y));
+        for (int m = 0; m < R3 / 2; ++m) asm volatile("" ::"v"(tw3[m].x), "v"(tw3[m].y));
+    }
     const double in_scale = p.in_scale;
 
     const int q1 = t / R3, m2 = t % R3;     // pass 2: (q1, m2); pass 3: (q2, g3) -- the same split
@@ -136,21 +143,28 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
 #ifndef RTLWS_F64_ABL_NOLDS
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) ldsd[rev16(s) * F64F_ROW + (t >> 4) * 17 + (t & 15)] = v[s];
+            for (int s = 0; s < 16; ++s)
+                ldsd[rev16(s) * F64F_ROW + (q1 / J) * 17 + (q1 % J) * R3 + m2] = v[s];
             __syncthreads();
 
-            // ---- pass 3: lane (q2, g3) = (t / 4, t % 4): sixteen contiguous elements, four
-            // twiddled radix-4 butterflies in fused-multiply-add form
+            // ---- pass 3: lane (q2, g3) = (t / R3, t % R3): sixteen contiguous elements, J
+            // twiddled radix-R3 butterflies in fused-multiply-add form
+            if constexpr (!TW3_REGS) {
+                const double2* tp = p.tw2f + (t / R3) * (R3 / 2);
+                asm volatile("" : "+v"(tp));          // not hoisted out of the frame loop
+#pragma unroll
+                for (int m = 0; m < R3 / 2; ++m) tw3[m] = tp[m];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = ldsd[q1 * F64F_ROW + m2 * 17 + i];
 #endif
 #pragma unroll
             for (int j = 0; j < J; ++j) fft_last<R3>(v, j * R3, tw3);
 
-            // ---- |X|^2, accumulate; slot u = j*4 + s holds bin k = 256*s + 4*t + j
+            // ---- |X|^2, accumulate; slot u = j*R3 + s holds bin k = 256*rev_last(s) + J*t + j
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                if (u == 15) {      // bin N-1 (lane 63) also feeds the DC slot, weight K - kf
+                if (u == 15) {      // bin N-1 (thread T-1) also feeds the DC slot, weight K - kf
                     const double pw = fma(v[u].y, v[u].y, v[u].x * v[u].x);
                     acc[u] = KONE ? pw : acc[u] + pw;
                     wdc = KONE ? pw : fma((double)(K - kf), pw, wdc);
@@ -162,13 +176,20 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
             }
         }
 
-        // ---- DC-slot rule (src/spectrum.c:25-33): slot N/2 (bin 0: lane 0, u = 0) takes
-        // sum_k (K-k) * P_k[N-1] (bin N-1: lane 63, u = 15)
-        {
+        // ---- DC-slot rule (src/spectrum.c:25-33): slot N/2 (bin 0: thread 0, u = 0) takes
+        // sum_k (K-k) * P_k[N-1] (bin N-1: thread T-1, u = 15)
+        if constexpr (T == 64) {
             const unsigned long long b = __builtin_bit_cast(unsigned long long, wdc);
             const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, 63);
             const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
             const double dcv = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            if (t == 0) acc[0] = dcv;
+        } else {
+            double* slot = reinterpret_cast<double*>(ldsd + f64_fused_lds_elems(N) - 1);
+            __syncthreads();
+            if (t == T - 1) *slot = wdc;
+            __syncthreads();
+            const double dcv = *slot;
             if (t == 0) acc[0] = dcv;
         }
 
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
         if constexpr (OUT == OUT_PAYLOAD) {
 #pragma unroll
             for (int s = 0; s < R3; ++s) {
-                const int i0 = 256 * (s ^ (R3 / 2)) + J * t;
+                const int i0 = 256 * (rev_last<R3>(s) ^ (R3 / 2)) + J * t;
                 unsigned packed = 0;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
@@ -191,9 +212,13 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
                     const unsigned m = (d >= 0.0) ? (d <= 255.0 ? (unsigned)(int)d : 255u) : 0u;
                     packed |= m << (8 * j);
                 }
-                *reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(p.out) + g * N + i0) = packed;
+                uint8_t* dst = reinterpret_cast<uint8_t*>(p.out) + g * N + i0;
+                if constexpr (J == 4) *reinterpret_cast<unsigned*>(dst) = packed;
+                else if constexpr (J == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
+                else *dst = (uint8_t)packed;
             }
-        } else {
+        } else if constexpr (J == 4) {
+            // N = 1024: a lane owns four consecutive bins = 32 bytes -> staged (above)
             __syncthreads();   // this row's pass-3 reads are done (wave-private: LDS ordering only)
 #pragma unroll
             for (int s = 0; s < R3; ++s) {
@@ -225,34 +250,74 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_fused(const SpectraParamsF6
 #endif
                 }
             }
+        } else {
+            // N = 2048 / 4096: a lane owns 2 / 1 consecutive bins per s: every store instruction
+            // already writes consecutive bytes (16 / 8 per lane)
+#pragma unroll
+            for (int s = 0; s < R3; ++s) {
+                const int i0 = 256 * (rev_last<R3>(s) ^ (R3 / 2)) + J * t;
+                double o[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    o[j] = acc[j * R3 + s];
+                    if constexpr (OUT == OUT_DB) o[j] = 10.0 * log10(o[j] / (double)p.count);
+                }
+                double* dst = reinterpret_cast<double*>(p.out) + g * N + i0;
+                if constexpr (J == 2) {
+                    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                    const nt_d2 v2 = {o[0], o[1]};
+                    __builtin_nontemporal_store(v2, reinterpret_cast<nt_d2*>(dst));
+                } else {
+                    __builtin_nontemporal_store(o[0], dst);
+                }
+            }
         }
     }
 }
 
-template <bool WIN, int OUT>
+template <int N, bool WIN, int OUT>
 static hipError_t launch_f64f_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
-    const size_t lds_bytes = f64_fused_lds_bytes();
+    const size_t lds_bytes = f64_fused_lds_bytes(N);
+    if (lds_bytes > 64 * 1024) {       // N = 4096: 69.6 KiB per workgroup
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_fused<N, WIN, OUT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_fused<N, WIN, OUT, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     if (p.k_avg == 1)
-        hipLaunchKernelGGL((spectra_f64_fused<WIN, OUT, true>), dim3(blocks), dim3(64), lds_bytes, st, p);
+        hipLaunchKernelGGL((spectra_f64_fused<N, WIN, OUT, true>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
     else
-        hipLaunchKernelGGL((spectra_f64_fused<WIN, OUT, false>), dim3(blocks), dim3(64), lds_bytes, st, p);
+        hipLaunchKernelGGL((spectra_f64_fused<N, WIN, OUT, false>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
     return hipGetLastError();
 }
 
-template <bool WIN>
+template <int N, bool WIN>
 static hipError_t launch_f64f_o(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
     switch (p.out_mode) {
-    case OUT_SUM: return launch_f64f_k<WIN, OUT_SUM>(p, blocks, st);
-    case OUT_DB: return launch_f64f_k<WIN, OUT_DB>(p, blocks, st);
-    default: return launch_f64f_k<WIN, OUT_PAYLOAD>(p, blocks, st);
+    case OUT_SUM: return launch_f64f_k<N, WIN, OUT_SUM>(p, blocks, st);
+    case OUT_DB: return launch_f64f_k<N, WIN, OUT_DB>(p, blocks, st);
+    default: return launch_f64f_k<N, WIN, OUT_PAYLOAD>(p, blocks, st);
     }
 }
 
-hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64& p, int blocks, hipStream_t st)
+template <int N>
+static hipError_t launch_f64f_w(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
-    return p.window ? launch_f64f_o<true>(p, blocks, st) : launch_f64f_o<false>(p, blocks, st);
+    return p.window ? launch_f64f_o<N, true>(p, blocks, st) : launch_f64f_o<N, false>(p, blocks, st);
+}
+
+hipError_t launch_spectra_f64_fused(const SpectraParamsF64& p, int blocks, hipStream_t st)
+{
+    switch (p.n_fft) {
+    case 1024: return launch_f64f_w<1024>(p, blocks, st);
+    case 2048: return launch_f64f_w<2048>(p, blocks, st);
+    case 4096: return launch_f64f_w<4096>(p, blocks, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace rtlws

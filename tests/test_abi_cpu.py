@@ -172,3 +172,7 @@ def test_f64_fused_lds_layout_is_conflict_free():
         sys.argv = argv
     assert lds_sim.analyse_f64(68, 17, verbose=False) == (128, 64, 128, 64)
     assert lds_sim.analyse_f64(64, 16, verbose=False)[1] > 64          # the unpadded layout conflicts
+    # the multi-wavefront sizes: rows of 17*R3, groups of 17 -- every access pattern at its ideal
+    for N in (2048, 4096):
+        per_wave = lds_sim.analyse_f64_n(N, verbose=False)
+        assert all(w == (128, 64, 128, 64) for w in per_wave), (N, per_wave)

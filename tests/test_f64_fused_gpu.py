@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 STRICT_F64 = 1e-10
 
 
-def _old_kernel(engine, iq, **kw):
+def _old_kernel(engine, iq, n_fft=1024, **kw):
     os.environ["RTLWS_F64_FUSED"] = "0"
     try:
-        return engine.spectra(iq, 1024, f64=True, **kw)
+        return engine.spectra(iq, n_fft, f64=True, **kw)
     finally:
         os.environ.pop("RTLWS_F64_FUSED", None)
 
@@ -61,3 +61,42 @@ def test_f64_fused_few_rows_and_dc_weights(engine, oracle):
         got = engine.spectra(iq, 1024, k_avg=k, f64=True)
         ref = oracle.batch_spectra_u8(iq, 1024, K=k)
         assert rel_err(got, ref, EPS_STRICT).max() <= STRICT_F64
+
+
+@pytest.mark.parametrize("N", [2048, 4096])
+@pytest.mark.parametrize("window,k_avg,output", [("rect", 1, "power_sum"), ("hann", 8, "mean_db"),
+                                                  ("hann", 1, "power_sum"), ("rect", 6, "payload_u8"),
+                                                  ("hann", 3, "payload_u8")])
+def test_f64_fused_2048_and_4096(engine, oracle, N, window, k_avg, output):
+    """The multi-wavefront sizes (two / four wavefronts per frame, barriers, LDS DC slot, direct
+    stores): strict metric against the oracle, payload bytes identical, and agreement with the
+    row-per-workgroup kernel."""
+    from rtlws import synth
+    rows = 2 * 256 * (8 // (N // 1024)) // 8 + 3          # more rows than resident workgroups, ragged
+    iq = synth.tone_noise_iq(rows * k_avg, N, seed=N + k_avg)
+    iq[1] = 128
+    iq[2] = synth.pure_tone_iq(1, N, seed=5)[0]
+    got = engine.spectra(iq, N, k_avg=k_avg, window=window, output=output, gain_db=15, f64=True)
+    w = synth.hann(N) if window == "hann" else None
+    ref = oracle.batch_spectra_u8(iq, N, K=k_avg, window=w, nthreads=8)
+    if output == "payload_u8":
+        want = np.stack([oracle.spectrum_payload(r, k_avg, 15) for r in ref])
+        assert got.dtype == np.uint8 and np.array_equal(got, want)
+    elif output == "mean_db":
+        ok = ref > 0
+        assert np.abs(got[ok] - 10 * np.log10(ref[ok] / k_avg)).max() <= 1e-9
+    else:
+        assert got.dtype == np.float64 and rel_err(got, ref, EPS_STRICT).max() <= STRICT_F64
+        old = _old_kernel(engine, iq[:16 * k_avg], N, k_avg=k_avg, window=window)
+        assert rel_err(got[:16], old, EPS_STRICT).max() <= STRICT_F64
+        if k_avg == 1:
+            assert np.array_equal(got[:, N // 2], got[:, N // 2 - 1])
+
+
+def test_f64_fused_config3_shape(engine, oracle):
+    """BASELINE.json configs[2] in the reference's precision: 4096-point Hann, K = 8, mean dB."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(8 * 40, 4096, seed=3)
+    got = engine.spectra(iq, 4096, k_avg=8, window="hann", output="mean_db", f64=True)
+    ref = oracle.batch_spectra_u8(iq, 4096, K=8, window=synth.hann(4096), nthreads=8)
+    assert np.abs(got - 10 * np.log10(ref / 8)).max() <= 1e-9

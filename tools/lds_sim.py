@@ -285,6 +285,27 @@ def analyse_f64(row=68, grp=17, verbose=True):
     return w1, r1, w2, r2
 
 
+def analyse_f64_n(N, verbose=True):
+    """spectrum_f64_fused.hip at N = 2048 / 4096: rows of 17*R3 double2, reader groups of 17."""
+    T, R3 = N // 16, N // 256
+    J = 16 // R3
+    row = 17 * R3
+    res = []
+    for wave in range(T // 64):
+        lanes = [wave * 64 + l for l in range(64)]
+        w1 = sum(cycles([2 * (rev16(s) * row + t) for t in lanes], W128, 4, 32) for s in range(16))
+        r1 = sum(cycles([2 * ((t // R3) * row + R3 * r2 + t % R3) for t in lanes], R128, 4, 64) for r2 in range(16))
+        w2 = sum(cycles([2 * (rev16(s) * row + ((t // R3) // J) * 17 + ((t // R3) % J) * R3 + t % R3) for t in lanes],
+                        W128, 4, 32) for s in range(16))
+        r2 = sum(cycles([2 * ((t // R3) * row + (t % R3) * 17 + i) for t in lanes], R128, 4, 64) for i in range(16))
+        res.append((w1, r1, w2, r2))
+        if verbose:
+            print("f64 N=%d wave %d: write1 %d (128) read1 %d (64) write2 %d (128) read2 %d (64)" % (N, wave, w1, r1, w2, r2))
+    return res
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "f64":
     analyse_f64()
     analyse_f64(64, 16)
+    analyse_f64_n(2048)
+    analyse_f64_n(4096)

@@ -16,8 +16,10 @@
 //
 // Cost model (MI355X): v_fma_f64 / v_add_f64 / v_mul_f64 issue at 4 cycles per wave64
 // instruction -- half the f32 rate, and the rate ONE wavefront can issue at by itself, so 2
-// wavefronts per SIMD are enough; ~560 of them per frame = 560 CU-cycles at 4 SIMDs.
-// Algorithmic bytes: 2N in + 8N/K out = 10 240 B per spectrum at K = 1.
+// wavefronts per SIMD are enough; ~420 of them (plus ~130 integer / address instructions) per
+// 1024-point frame.  Algorithmic bytes: 2N in + 8N/K out = 10 240 B per 1024-point spectrum at
+// K = 1; the kernel is bound by that traffic (4/5 of it stores), not by the
+// arithmetic: 100 us per 65 536 frames with no stores, 135 us with them.
 //
 // LDS (double2 units, one buffer reused by both transpositions; tools/lds_sim.py f64;
 // ROW = 17*R3 = 68 / 136 / 272):
@@ -196,10 +198,9 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
         // ---- epilogue + store.  For each s the wavefront covers 256 consecutive outputs and a
         // lane owns four of them (bins 4t .. 4t+3): 32 bytes, i.e. two 16-byte stores that would
         // each leave every other 16 bytes of a line unwritten -- measured 1.58x the output bytes
-        // at the HBM and 286 us per launch against 100 us with no stores at all.  The rows of
-        // doubles therefore go through the (idle) transposition buffer once more, so that every
-        // store instruction writes 1 KiB of consecutive bytes: lane l the l-th 16 bytes.
-        // fft-shift = flip the top bit of the bin index.
+        // at the HBM and 286 us per launch against 100 us with no stores at all.  The two halves
+        // of the wavefront therefore trade pieces first (below), so that every store instruction
+        // writes 1 KiB of consecutive bytes.  fft-shift = flip the top bit of the bin index.
         if constexpr (OUT == OUT_PAYLOAD) {
 #pragma unroll
             for (int s = 0; s < R3; ++s) {
@@ -218,8 +219,13 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
                 else *dst = (uint8_t)packed;
             }
         } else if constexpr (J == 4) {
-            // N = 1024: a lane owns four consecutive bins = 32 bytes -> staged (above)
-            __syncthreads();   // this row's pass-3 reads are done (wave-private: LDS ordering only)
+            // N = 1024: a lane owns four consecutive bins = 32 bytes = 16-byte pieces A_t | B_t.
+            // v_permlane32_swap exchanges the upper 32 lanes of A with the lower 32 lanes of B:
+            // afterwards one register holds A_0..31 | B_0..31 -- the first 1 KiB of the block, every
+            // 16-byte slot once -- and the other A_32..63 | B_32..63, the second KiB (lane l holds
+            // slot 2*(l & 31) + (l >> 5) of its KiB).  No LDS, no wait.
+            typedef double nt_d2 __attribute__((ext_vector_type(2)));
+            const int slot = 2 * (t & 31) + (t >> 5);
 #pragma unroll
             for (int s = 0; s < R3; ++s) {
                 double o[J];
@@ -228,27 +234,28 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
                     o[j] = acc[j * R3 + s];
                     if constexpr (OUT == OUT_DB) o[j] = 10.0 * log10(o[j] / (double)p.count);
                 }
-                ldsd[128 * s + 2 * t] = mk(o[0], o[1]);
-                ldsd[128 * s + 2 * t + 1] = mk(o[2], o[3]);
-            }
-            __syncthreads();
-            typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                double x[2], y[2];
 #pragma unroll
-            for (int s = 0; s < R3; ++s) {
-                nt_d2* dst = reinterpret_cast<nt_d2*>(reinterpret_cast<double*>(p.out) + g * N + 256 * (s ^ (R3 / 2)));
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const f2 x = ldsd[128 * s + 64 * half + t];
-                    const nt_d2 v2 = {x.x, x.y};
-#if defined(RTLWS_F64_ABL_NOSTORE)   // timing-only build: values kept live, nothing stored
-                    if (p.k_avg == 12345) dst[64 * half + t] = v2;
-                    else asm volatile("" ::"v"(x.x), "v"(x.y));
-#elif defined(RTLWS_F64_PLAIN_STORE)
-                    dst[64 * half + t] = v2;
-#else
-                    __builtin_nontemporal_store(v2, dst + 64 * half + t);
-#endif
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned long long ab = __builtin_bit_cast(unsigned long long, o[h]);
+                    const unsigned long long bb = __builtin_bit_cast(unsigned long long, o[2 + h]);
+                    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
+                    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+                    x[h] = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+                    y[h] = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
                 }
+                nt_d2* dst = reinterpret_cast<nt_d2*>(reinterpret_cast<double*>(p.out) + g * N + 256 * (s ^ (R3 / 2)));
+                const nt_d2 vx = {x[0], x[1]}, vy = {y[0], y[1]};
+#if defined(RTLWS_F64_ABL_NOSTORE)   // timing-only build: values kept live, nothing stored
+                if (p.k_avg == 12345) { dst[slot] = vx; dst[64 + slot] = vy; }
+                else asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+#elif defined(RTLWS_F64_PLAIN_STORE)
+                dst[slot] = vx;
+                dst[64 + slot] = vy;
+#else
+                __builtin_nontemporal_store(vx, dst + slot);
+                __builtin_nontemporal_store(vy, dst + 64 + slot);
+#endif
             }
         } else {
             // N = 2048 / 4096: a lane owns 2 / 1 consecutive bins per s: every store instruction

@@ -34,7 +34,8 @@ def _small_frames(bench, name):
 
 @pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt",
                                   "cic10_2048pt", "k6_1024pt_payload", "cic8_block_sums",
-                                  "batched_1024pt_64k_frames_f64"])
+                                  "batched_1024pt_64k_frames_f64", "hann_4096pt_k8_db_f64", "rect_2048pt_f64",
+                                  "rect_4096pt", "hann_4096pt_k1_db"])
 def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeypatch):
     import bench
     monkeypatch.setattr(bench, "SETTLE_LAUNCHES", 40)        # the ordering matters here, not the governor
@@ -51,6 +52,14 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
         assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
         assert r["dtype"] == ("int32" if name == "cic8_block_sums" else ("f64" if f64 else "f32"))
     assert runs[0]["parity"] == runs[1]["parity"]             # same seed, same kernel: identical statistics
+
+
+def test_run_workload_uniform_input_variant(ctx):
+    """SURVEY.md §8d's other input: uniform random bytes (bench.py --input uniform)."""
+    import bench
+    c = dict(ctx, input="uniform")
+    r = bench.run_workload(c, "batched_1024pt_64k_frames", steps=4, warmup=0, sets=2, frames_override=1024)
+    assert "uniform" in r["config"]["input"] and "failed" not in r["parity"]
 
 
 def test_torch_default_stream_handle_is_mapped(built):

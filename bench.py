@@ -595,13 +595,17 @@ def plumbing_main(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.002 * (rank + 1))
+    own = time.perf_counter() - t0                 # this rank's steps, before waiting for the others
     if dist is not None:
         dist.barrier()
     elapsed, slowest = max_over_ranks(torch, dist, [time.perf_counter() - t0, float(rank)])
+    per_rank_own = gather_ranks(torch, dist, 1e3 * own / args.steps)
     if rank == 0:
         print(json.dumps({"metric": "plumbing only (no GPU step)", "value": whole_job_rate(world, args.steps, frames, elapsed),
                           "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
-                          "slowest_rank": slowest, "asked_gpus": args.gpus, "data": "none"}), flush=True)
+                          "slowest_rank": slowest, "asked_gpus": args.gpus, "data": "none",
+                          "per_rank": {"ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
+                                                           "all": per_rank_own}}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -85,6 +85,11 @@ def test_bench_gpus_n_fans_out_by_itself():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["asked_gpus"] == 2 and res["slowest_rank"] == 1.0
     assert abs(res["value"] - 2 * 5 * 65536 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-9
+    # every rank's own time is in the line: rank 1 sleeps twice as long as rank 0, and the job's
+    # ms_per_step (MAX over ranks, closing barrier included) is at least the slow rank's own
+    own = res["per_rank"]["ms_per_step_own"]
+    assert len(own["all"]) == 2 and own["min"] == own["all"][0] < own["all"][1] == own["max"] <= res["ms_per_step"] * 1.001
+    assert 1.5 < own["all"][1] / own["all"][0] < 2.6
 
 
 def test_bench_gpus_n_without_the_devices_fails_loudly():

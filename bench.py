@@ -219,7 +219,7 @@ def fan_out(gpus, argv, plumbing_cpu=False):
 
 # ---- one workload: settle, time K steps, price against HBM --------------------
 
-def parity_block(np, po, wl, host_in, got, nchk):
+def parity_block(np, po, wl, host_in, got, nchk, f64=False):
     n_fft, k_avg, window, output, cic_r, _ = wl
     if output == "cs32":
         want = (host_in.astype(np.int32) - 128).reshape(-1, cic_r, 2).sum(axis=1).reshape(nchk, -1)
@@ -232,8 +232,17 @@ def parity_block(np, po, wl, host_in, got, nchk):
                                   window=None if window == "rect" else
                                   (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)))
     if output == "mean_db":
-        ref = 10 * np.log10(ref / k_avg)
-        return {"frames": nchk, "max_abs_db_err": float(np.abs(got - ref).max())}
+        with np.errstate(divide="ignore"):
+            ref_db = 10 * np.log10(ref / k_avg)
+        err = np.abs(got - ref_db)
+        err[~np.isfinite(ref_db) & ~np.isfinite(got)] = 0.0          # log(0) on both sides (constant frames)
+        if k_avg == 1 and not f64:
+            # single f32 frames: the budget is stated for bins within 50 dB of the row maximum
+            # (1e-4 relative = 4.3e-4 dB); the rest is reported, not bounded
+            strong = ref >= 1e-5 * ref.max(axis=1, keepdims=True)
+            return {"frames": nchk, "max_abs_db_err_within_50db": float(err[strong].max()),
+                    "max_abs_db_err_all_bins": float(err.max())}
+        return {"frames": nchk, "max_abs_db_err": float(err.max())}
     if output == "payload_u8":
         want = np.stack([po.spectrum_payload(r, k_avg, 0) for r in ref])
         diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
@@ -261,7 +270,7 @@ def parity_block(np, po, wl, host_in, got, nchk):
 # what a parity block must hold for the line to be printed with exit code 0 (the f32 batch
 # kernel's budget, DESIGN.md §5: the same bounds tests/ assert)
 PARITY_BOUNDS = {"max_rel_err_floor1e-5": 1e-4, "max_rel_err_floor1e-9": 5e-3, "p99.9_rel_err_floor1e-9": 1e-4,
-                 "max_abs_db_err": 2e-4, "max_byte_diff": 1}
+                 "max_abs_db_err": 2e-4, "max_abs_db_err_within_50db": 4.4e-4, "max_byte_diff": 1}
 PARITY_BOUNDS_F64 = {"max_rel_err_floor1e-9": 1e-10, "max_abs_db_err": 1e-9}
 
 
@@ -438,7 +447,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         nchk = 256 * k_avg
         host_in = ins[0][:nchk].cpu().numpy()
         got = outs[0][:nchk if cic_only else 256].cpu().numpy()
-        result["parity"] = parity_block(np, po, wl, host_in, got, nchk)
+        result["parity"] = parity_block(np, po, wl, host_in, got, nchk, f64)
         bad = parity_failures(result["parity"], PARITY_BOUNDS_F64 if f64 else None)
         if bad:
             result["parity"]["failed"] = bad

@@ -6,7 +6,10 @@ For a workload: the vector-issue cycles one launch needs on a SIMD,
 from rocprofv3's SQ_INSTS_VALU per launch (profiles/r03_<workload>_pmc.json) split by class with
 the kernel's own ISA (hipcc -S; tools/isa_hist.py): plain f32 / integer VALU 2 cycles, conversions
 and SDWA 4, every f64 instruction 4 (tools/valubench.hip, measured on gfx950) -- and the shader
-clock rocm-smi showed under sustained load of that workload (profiles/r03_power_clocks.txt).
+clock the workload runs at: measured IN the kernel where the kernel has the stamped diagnostic
+build (tools/inkernel_clock.py: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over workgroups
+after 2.5 s of back-to-back launches; profiles/r03_inkernel_clock.json), rocm-smi's sclk under
+sustained load otherwise (profiles/r03_power_clocks.txt; it can read up to ~10 % high).
 bench.py divides by the SIMD-cycles its own launch lasted: 4 SIMDs x CUs x launch time x sclk.
 
 usage: make_valu_insts.py profiles/valu_insts.json
@@ -35,18 +38,20 @@ def entry(workload, frames, four_cycle_per_frame, sclk_ghz, note):
 def main():
     out = {
         # 4 wavefronts x 32 v_cvt_f32_ubyteN per frame
-        "hann_4096pt_k8_db": entry("hann_4096pt_k8_db", 16384, 128, 2.198,
+        "hann_4096pt_k8_db": entry("hann_4096pt_k8_db", 16384, 128, 2.188,
                                    "spectra_fused<4096, u8, Hann, dB, K>1>: 128 byte conversions per frame at 4 cycles; "
-                                   "sclk 2.194-2.202 GHz at 1 354-1 372 W (profiles/r03_power_clocks.txt)"),
+                                   "in-kernel clock 2.188 GHz median (p10-p90 2.163-2.217; profiles/r03_inkernel_clock.json); "
+                                   "rocm-smi 2.194-2.202 GHz at 1 354-1 372 W"),
         # 1 wavefront x 32 conversions per frame
-        "batched_1024pt_64k_frames": entry("batched_1024pt_64k_frames", 65536, 32, 1.886,
+        "batched_1024pt_64k_frames": entry("batched_1024pt_64k_frames", 65536, 32, 2.007,
                                            "spectra_fused<1024, u8, rect, sum, K=1>: 32 byte conversions per frame at 4 "
-                                           "cycles; sclk 1.884-1.892 GHz at 1 394-1 402 W (the cap)"),
+                                           "cycles; in-kernel clock 2.007 GHz median (p10-p90 1.936-2.078; another box's "
+                                           "rocm-smi: 1.884-1.892 GHz at 1 394-1 402 W, the cap)"),
         # per frame (one wavefront): 386 f64 arithmetic + 32 conversions to f64 + 32 SDWA integer adds at 4 cycles
         "batched_1024pt_64k_frames_f64": entry("batched_1024pt_64k_frames_f64", 65536, 386 + 32 + 32, 2.03,
                                                "spectra_f64_fused<rect, sum, K=1>: 386 f64 add / mul / fma, 32 "
-                                               "v_cvt_f64_*, 32 SDWA integer adds per frame at 4 cycles; sclk "
-                                               "2.02-2.05 GHz at 1 375-1 382 W"),
+                                               "v_cvt_f64_*, 32 SDWA integer adds per frame at 4 cycles; rocm-smi sclk "
+                                               "2.02-2.05 GHz at 1 375-1 382 W (no stamped build of this kernel)"),
     }
     json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
     for k, v in out.items():

@@ -191,18 +191,27 @@ constexpr int fused_lds_bytes(int n_fft, int in_kind, bool win)
     return (st > tr ? st : tr) + pf;
 }
 
-// ---- spectrum_fused_v2.hip: 4096-point cmplx_u8 frames, two virtual threads per lane ----
-// LDS in float2 units: transposition 2 is the larger (q2 stride 290, q1 stride 18) + the DC slot
-constexpr int v2_lds_f2(int n_fft) { return n_fft == 4096 ? 15 * 290 + 15 * 18 + 16 + 2 : 0; }
+// ---- spectrum_fused_v2.hip: 4096- / 2048-point cmplx_u8 frames, two virtual threads per lane ----
+// transposition 2: q2 stride (chosen with the pass-3 lane map so that reads are conflict-free)
+constexpr int v2_a2(int n_fft) { return n_fft == 4096 ? 290 : 146; }
+// LDS in float2 units: transposition 2 is the larger (q2 stride A2, groups of 16 padded to 18) + the DC slot
+constexpr int v2_lds_f2(int n_fft)
+{
+    return 15 * v2_a2(n_fft) + (n_fft / 256 - 1) * 18 + (16 / (n_fft / 256) - 1) * (n_fft / 256) + (n_fft / 256) + 2;
+}
 constexpr int v2_lds_bytes(int n_fft) { return 8 * v2_lds_f2(n_fft); }
-// 2 wavefronts per workgroup, 2 per SIMD (256 VGPRs): 4 workgroups per CU, which is also what the LDS holds
-constexpr int v2_blocks_per_cu(int n_fft) { return 163840 / v2_lds_bytes(n_fft) < 4 ? 163840 / v2_lds_bytes(n_fft) : 4; }
+// 2 wavefronts per SIMD (256 VGPRs) = 8 per CU: 4 two-wavefront workgroups at N = 4096, 8 one-wavefront
+// ones at 2048 -- which is also what the LDS holds
+constexpr int v2_blocks_per_cu(int n_fft)
+{
+    return 163840 / v2_lds_bytes(n_fft) < 8 / (n_fft / 2048) ? 163840 / v2_lds_bytes(n_fft) : 8 / (n_fft / 2048);
+}
 // which descriptors take it (the shim may override with RTLWS_V2=0|1 for A/B runs)
 #ifndef RTLWS_V2_DEFAULT
 #define RTLWS_V2_DEFAULT 1
 #endif
-constexpr bool fused_v2_kind(int n_fft, int in_kind) { return n_fft == 4096 && in_kind == IN_CU8; }
-hipError_t launch_spectra_fused_v2_4096(const SpectraParams&, int blocks, hipStream_t);
+constexpr bool fused_v2_kind(int n_fft, int in_kind) { return (n_fft == 4096 || n_fft == 2048) && in_kind == IN_CU8; }
+hipError_t launch_spectra_fused_v2(const SpectraParams&, int blocks, hipStream_t);
 
 hipError_t launch_spectra_fused_1024(const SpectraParams&, int in_kind, int blocks, hipStream_t);
 hipError_t launch_spectra_fused_2048(const SpectraParams&, int in_kind, int blocks, hipStream_t);

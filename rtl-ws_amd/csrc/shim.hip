@@ -632,13 +632,11 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     if (fused) {
         const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
                                         d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
-        switch (d->n_fft) {
+        if (use_v2(d->n_fft, in_kind, d->k_avg)) err = rtlws::launch_spectra_fused_v2(p, blocks, st);
+        else switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
         case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;
-        default:
-            err = use_v2(d->n_fft, in_kind, d->k_avg) ? rtlws::launch_spectra_fused_v2_4096(p, blocks, st)
-                                            : rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st);
-            break;
+        default: err = rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st); break;
         }
     } else {
         if (in_kind >= rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8;     // the direct kernel sums R bytes itself

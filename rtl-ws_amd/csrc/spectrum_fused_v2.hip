@@ -1,8 +1,9 @@
-// spectrum_fused_v2.hip -- the 4096-point cmplx_u8 fused kernel with TWO virtual
-// threads per lane: 128 threads (two wavefronts) own one frame and every lane holds
-// 32 complex points -- the same radix-16 x 16 x 16 decomposition, tables, twiddle
-// forms and arithmetic as spectrum_fused.hip (whose "virtual thread" vt = 2t + h is
-// one of that kernel's 256 threads), so results are bit-identical to it.
+// spectrum_fused_v2.hip -- the 4096- and 2048-point cmplx_u8 fused kernels with TWO
+// virtual threads per lane: N/32 threads own one frame (two wavefronts at N = 4096, ONE at
+// 2048 -- no barrier at all there) and every lane holds 32 complex points -- the same
+// radix-16 x 16 x R3 decomposition, tables, twiddle forms and arithmetic as
+// spectrum_fused.hip (whose "virtual thread" vt = 2t + h is one of that kernel's N/16
+// threads), so results are bit-identical to it.
 //
 // Why (VERDICT r2 "next" #2, DESIGN.md §6 configs[2]): the 256-thread form spends
 // half of a frame's cycles not issuing vector instructions -- four wavefronts meet at
@@ -21,14 +22,14 @@
 // dB / payload epilogue of src/cbb_main.c:121-130.
 //
 // LDS layouts (float2 units; tools/lds_sim.py v2):
-//   transposition 1  (q1, m1) at q1*272 + m1             -- as spectrum_fused.hip
-//   transposition 2  (q1, m2, q2) at q2*290 + q1*18 + m2 -- rows of 18 as there, the
-//       q2 stride 290 instead of 288 (2*290 = 4 mod 64 dwords) so that a
-//       ds_read_b128 lane group -- 16 lanes {0-3,12-15,20-27}, ... -- that holds two
-//       sets of eight consecutive pairs from q2 rows of different parity covers the
-//       64 banks exactly once; pass 3 assigns pairs to lanes accordingly
-//       (pair_of_lane), which costs nothing: a wavefront still stores 512 contiguous
-//       bytes per instruction, in a permuted lane order.
+//   transposition 1  (q1, m1) at q1*(T+R3) + m1          -- as spectrum_fused.hip
+//   transposition 2  (q1, m2, q2) at q2*A2 + (q1/J)*18 + (q1%J)*R3 + m2 -- groups of 16
+//       padded to 18 as there, the q2 stride A2 = 290 (N = 4096) / 146 (N = 2048) instead
+//       of 18*R3, chosen with the pass-3 assignment of pairs to lanes (pair_of_lane) so
+//       that every ds_read_b128 lane group -- 16 lanes {0-3,12-15,20-27}, ... -- covers the
+//       64 banks exactly once.  The permutation costs nothing: a wavefront still stores
+//       512 (N = 4096) or 1 024 (N = 2048) contiguous bytes per instruction, in a
+//       permuted lane order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,16 +49,27 @@ namespace rtlws {
 #define RTLWS_V2_NT_STORE 1      // nontemporal float2 stores: +2.5..3.5 % (rows are written once, never re-read)
 #endif
 
-constexpr int V2_S1 = 272;       // transposition 1 row stride (T + R3)
-constexpr int V2_A2 = 290;       // transposition 2 q2 stride
-constexpr int V2_P2 = 18;        // transposition 2 q1 stride
+constexpr int V2_P2 = 18;        // transposition 2: padded group of 16
+constexpr int v2_s1(int n_fft) { return n_fft / 16 + n_fft / 256; }      // transposition 1 row stride (T + R3)
 
 // pass 3: which pair of adjacent virtual threads (2*pair, 2*pair + 1) a lane owns
+template <int N>
 __device__ __forceinline__ int pair_of_lane(int t)
 {
     const int l = t & 31;
-    const int s = l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l;
-    return (t & ~31) | s;
+    if constexpr (N == 4096) {
+        // 128 pairs, q2 = pair / 8: each read group holds two sets of eight consecutive pairs
+        // from q2 rows of different parity
+        const int s = l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l;
+        return (t & ~31) | s;
+    } else {
+        // 64 pairs, q2 = pair / 4: read group k (of the guide's four) holds pairs 8k .. 8k+7 and
+        // 32+8k .. 32+8k+7, i.e. q2 rows {2k, 2k+1, 8+2k, 9+2k}
+        const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+        const int idx = g1 ? (l < 12 ? l - 4 : l < 20 ? l - 8 : l - 16) : (l < 4 ? l : l < 16 ? l - 8 : l - 12);
+        const int k = 2 * (t >> 5) + (g1 ? 1 : 0);
+        return idx < 8 ? 8 * k + idx : 32 + 8 * k + (idx - 8);
+    }
 }
 
 template <int N>
@@ -109,9 +121,11 @@ __device__ __forceinline__ void ld_pair(const float2* src, f2& a, f2& b)
 template <int N, bool WIN, int OUT, bool KONE>
 __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParams p)
 {
-    static_assert(N == 4096, "the pass-3 lane map and the strides are the 4096-point ones");
+    static_assert(N == 4096 || N == 2048, "pass-3 lane maps and strides exist for these two sizes");
     constexpr int T = N / 16;      // virtual threads per frame
-    constexpr int R3 = N / 256;    // 16: radix of the last pass, one butterfly per virtual thread
+    constexpr int R3 = N / 256;    // radix of the last pass
+    constexpr int J = 16 / R3;     // last-pass butterflies per virtual thread
+    constexpr int V2_S1 = v2_s1(N), V2_A2 = v2_a2(N);
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
 
     const int t = threadIdx.x;     // owns virtual threads 2t, 2t + 1 in passes 1 and 2
@@ -129,9 +143,9 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int s = 0; s < 16; ++s) tw1[h][s] = p.tw1[(2 * t + h) * 16 + s];
-    const int pr = pair_of_lane(t);                   // pass 3: virtual threads 2*pr, 2*pr + 1
+    const int pr = pair_of_lane<N>(t);                // pass 3: virtual threads 2*pr, 2*pr + 1
 #pragma unroll
-    for (int m = 0; m < R3 / 2; ++m) tw3[m] = p.tw2[(pr / 8) * (R3 / 2) + m];     // q2 = (2*pr) / 16
+    for (int m = 0; m < R3 / 2; ++m) tw3[m] = p.tw2[((2 * pr) / R3) * (R3 / 2) + m];     // q2 = (2*pr) / R3
     float2 wcs[2];
     float win[2][16];
 #pragma unroll
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
     for (int m = 0; m < R3 / 2; ++m) asm volatile("" ::"v"(tw3[m].x), "v"(tw3[m].y));
     const float in_scale = p.in_scale;
 
-    const int q1 = t >> 3, mb = 2 * (t & 7);          // passes 1 -> 2: (q1, m2 = mb + h)
-    const int q2 = pr >> 3, gb = 2 * (pr & 7);        // pass 3: (q2, g3 = gb + h)
+    const int q1 = (2 * t) / R3, mb = (2 * t) % R3;   // passes 1 -> 2: (q1, m2 = mb + h)
+    const int q2 = (2 * pr) / R3, gb = (2 * pr) % R3; // pass 3: (q2, g3 = gb + h)
 
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         float acc[2][16];
@@ -207,7 +221,8 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
             fft16_sel(v[1]);
             __syncthreads();   // everyone has read transposition 1
 #pragma unroll
-            for (int s = 0; s < 16; ++s) st_pair(lds + rev16(s) * V2_A2 + q1 * V2_P2 + mb, v[0][s], v[1][s]);
+            for (int s = 0; s < 16; ++s)
+                st_pair(lds + rev16(s) * V2_A2 + (q1 / J) * V2_P2 + (q1 % J) * R3 + mb, v[0][s], v[1][s]);
             __syncthreads();
 
             // ---- pass 3: virtual thread (q2, g3): sixteen contiguous elements, twiddled radix-16
@@ -216,10 +231,13 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     ld_pair(lds + q2 * V2_A2 + (gb + h) * V2_P2 + 2 * i, v[h][2 * i], v[h][2 * i + 1]);
-            fft_last<R3>(v[0], 0, tw3);
-            fft_last<R3>(v[1], 0, tw3);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                fft_last<R3>(v[0], j * R3, tw3);
+                fft_last<R3>(v[1], j * R3, tw3);
+            }
 
-            // ---- |X|^2, accumulate; slot s holds bin k = 256*rev16(s) + 2*pr + h
+            // ---- |X|^2, accumulate; slot u = j*R3 + s holds bin k = 256*rev_last(s) + J*(2*pr + h) + j
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -248,38 +266,52 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
             if (pr == 0) acc[0][0] = dcv;
         }
 
-        // ---- epilogue + store: for each s the workgroup covers 256 consecutive outputs,
-        // a lane two of them; fft-shift = flip the top bit of the bin index
+        // ---- epilogue + store: for each s the workgroup covers 256 consecutive outputs, a lane
+        // 2*J of them (bins J*(2*pr + h) + j); fft-shift = flip the top bit of the bin index
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int i0 = 256 * (rev16(s) ^ (R3 / 2)) + 2 * pr;
-            float o[2];
+        for (int s = 0; s < R3; ++s) {
+            const int i0 = 256 * (rev_last<R3>(s) ^ (R3 / 2)) + 2 * J * pr;
+            float o[2 * J];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float a = acc[h][s];
-                constexpr float DB_PER_LOG2 = 3.01029995663981195f;
-                if constexpr (OUT == OUT_DB) a = fmaf(DB_PER_LOG2, __builtin_amdgcn_logf(a), p.db_offset);
-                if constexpr (OUT == OUT_PAYLOAD) a = DB_PER_LOG2 * __builtin_amdgcn_logf(fabsf(a * p.lin_gain));
-                o[h] = a;
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    float a = acc[h][j * R3 + s];
+                    constexpr float DB_PER_LOG2 = 3.01029995663981195f;
+                    if constexpr (OUT == OUT_DB) a = fmaf(DB_PER_LOG2, __builtin_amdgcn_logf(a), p.db_offset);
+                    if constexpr (OUT == OUT_PAYLOAD) a = DB_PER_LOG2 * __builtin_amdgcn_logf(fabsf(a * p.lin_gain));
+                    o[h * J + j] = a;
+                }
             if constexpr (OUT == OUT_PAYLOAD) {
                 unsigned packed = 0;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float d = o[h];      // (int) truncation toward zero, then clamp; NaN/-inf -> 0
+                for (int i = 0; i < 2 * J; ++i) {
+                    const float d = o[i];      // (int) truncation toward zero, then clamp; NaN/-inf -> 0
                     const unsigned m = (d >= 0.0f) ? (d <= 255.0f ? (unsigned)(int)d : 255u) : 0u;
-                    packed |= m << (8 * h);
+                    packed |= m << (8 * i);
                 }
-                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(p.out) + g * N + i0) = (uint16_t)packed;
+                uint8_t* dst = reinterpret_cast<uint8_t*>(p.out) + g * N + i0;
+                if constexpr (J == 2) *reinterpret_cast<unsigned*>(dst) = packed;
+                else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
             } else {
                 float* dst = reinterpret_cast<float*>(p.out) + g * N + i0;
+                if constexpr (J == 2) {
 #if RTLWS_V2_NT_STORE
-                typedef float nt_f2 __attribute__((ext_vector_type(2)));
-                const nt_f2 ov = {o[0], o[1]};
-                __builtin_nontemporal_store(ov, reinterpret_cast<nt_f2*>(dst));
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const nt_f4 ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(dst));
 #else
-                *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
 #endif
+                } else {
+#if RTLWS_V2_NT_STORE
+                    typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                    const nt_f2 ov = {o[0], o[1]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<nt_f2*>(dst));
+#else
+                    *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+#endif
+                }
             }
         }
     }
@@ -306,8 +338,10 @@ static hipError_t launch_v2_o(const SpectraParams& p, int blocks, hipStream_t st
     }
 }
 
-hipError_t launch_spectra_fused_v2_4096(const SpectraParams& p, int blocks, hipStream_t st)
+hipError_t launch_spectra_fused_v2(const SpectraParams& p, int blocks, hipStream_t st)
 {
+    if (p.n_fft == 2048)
+        return p.window ? launch_v2_o<2048, true>(p, blocks, st) : launch_v2_o<2048, false>(p, blocks, st);
     return p.window ? launch_v2_o<4096, true>(p, blocks, st) : launch_v2_o<4096, false>(p, blocks, st);
 }
 

@@ -160,6 +160,26 @@ def test_v2_pass3_lane_map_is_a_conflict_free_permutation():
     res = lds_sim.analyse_v2(4096, 272, 290, 18, verbose=False)
     assert all(r[:3] == (128, 64, 128) for r in res.values())         # writes and the pass-2 reads as well
 
+    # N = 2048 (one wavefront per frame): 64 pairs, q2 = pair / 4, strides (146, 18)
+    def pair_2048(t):
+        l = t & 31
+        g1 = (4 <= l < 12) or (16 <= l < 20) or l >= 28
+        idx = (l - 4 if l < 12 else l - 8 if l < 20 else l - 16) if g1 else (l if l < 4 else l - 8 if l < 16 else l - 12)
+        k = 2 * (t >> 5) + (1 if g1 else 0)
+        return 8 * k + idx if idx < 8 else 32 + 8 * k + (idx - 8)
+
+    assert sorted(pair_2048(t) for t in range(64)) == list(range(64))
+    assert pair_2048(0) == 0 and pair_2048(63) == 63
+    total = 0
+    for h in range(2):
+        for i in range(8):
+            addr = [((2 * pair_2048(t) + h) // 8) * 146 + ((2 * pair_2048(t) + h) % 8) * 18 + 2 * i for t in range(64)]
+            assert all(a % 2 == 0 for a in addr)
+            total += lds_sim.cycles(addr, lds_sim.R128, 4, 64)
+    assert total == 16 * 4
+    res = lds_sim.analyse_v2(2048, 136, 146, 18, verbose=False)
+    assert all(r[:3] == (128, 64, 128) for r in res.values())
+
 
 def test_f64_fused_lds_layout_is_conflict_free():
     """spectrum_f64_fused.hip: rows of 64 double2 padded to 68, reader groups of 16 padded to 17."""

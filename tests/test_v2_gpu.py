@@ -11,13 +11,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _both(engine, iq, **kw):
+def _both(engine, iq, n_fft=4096, **kw):
     old = os.environ.get("RTLWS_V2")
     try:
         os.environ["RTLWS_V2"] = "1"
-        a = engine.spectra(iq, 4096, **kw)
+        a = engine.spectra(iq, n_fft, **kw)
         os.environ["RTLWS_V2"] = "0"
-        b = engine.spectra(iq, 4096, **kw)
+        b = engine.spectra(iq, n_fft, **kw)
     finally:
         if old is None:
             os.environ.pop("RTLWS_V2", None)
@@ -54,3 +54,28 @@ def test_v2_small_and_ragged_grids(engine, oracle):
         a, b = _both(engine, iq)
         assert np.array_equal(a, b)
         assert rel_err(a, oracle.batch_spectra_u8(iq, 4096), EPS_K1).max() <= TOL
+
+
+@pytest.mark.parametrize("window", ["rect", "hann"])
+@pytest.mark.parametrize("k_avg,output", [(1, "power_sum"), (8, "mean_db"), (6, "payload_u8"), (3, "power_sum")])
+def test_v2_2048_bit_identical_to_the_two_wavefront_kernel(engine, built, oracle, window, k_avg, output):
+    """N = 2048: one wavefront per frame (no barrier), a lane's two virtual threads store four
+    consecutive outputs; every output bit-identical to spectrum_fused.hip's."""
+    from rtlws import synth
+    from helpers import rel_err, EPS_K1, TOL
+    rows = 2 * 8 * 256 + 5
+    iq = synth.tone_noise_iq(rows * k_avg, 2048, seed=21 + k_avg)
+    iq[5] = 128
+    iq[7] = synth.uniform_iq(1, 2048, seed=3)[0]
+    desc = built.make_desc(2048, k_avg, "cu8", window, output)
+    os.environ["RTLWS_V2"] = "1"
+    try:
+        rc, blocks, threads, lds = engine.grid(desc, rows * k_avg)
+    finally:
+        os.environ.pop("RTLWS_V2", None)
+    assert (rc, threads) == (0, 64) and lds == 8 * 2334 and blocks <= 8 * 256
+    a, b = _both(engine, iq, 2048, k_avg=k_avg, window=window, output=output)
+    assert a.shape == (rows, 2048) and np.array_equal(a, b, equal_nan=True)
+    if output == "power_sum" and k_avg == 1:
+        w = synth.hann(2048) if window == "hann" else None
+        assert rel_err(a[:64], oracle.batch_spectra_u8(iq[:64], 2048, window=w), EPS_K1).max() <= TOL

@@ -152,12 +152,23 @@ def whole_job_rate(world, steps, frames_per_step, elapsed_s):
 
 # ---- which device a rank uses ------------------------------------------------------
 
+def rehearsal():
+    """RTLWS_BENCH_REHEARSAL=1: the N-rank code path on a box with fewer GPUs than ranks -- the
+    ranks share devices (rank r on device r mod n) and rendezvous over gloo instead of RCCL (which
+    refuses two ranks on one device).  Everything else is the real thing: the GPU steps, the
+    barrier-bracketed timing, the MAX over ranks, the per-rank spread, the one JSON line.  The line
+    says so and its numbers are not a measurement."""
+    return os.environ.get("RTLWS_BENCH_REHEARSAL", "") == "1"
+
+
 def device_for_rank(local_rank, device_count):
     """One process per GPU: rank r of the node uses device r.  A rank without a device of
     its own is an error, never a silent share -- eight ranks on fewer devices would report
-    an 8-GPU rate that is not one."""
+    an 8-GPU rate that is not one.  (Except in a rehearsal, which is labelled as one.)"""
     if device_count < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if rehearsal():
+        return local_rank % device_count
     if not 0 <= local_rank < device_count:
         raise SystemExit("bench.py: LOCAL_RANK %d but this host has %d HIP device(s)" % (local_rank, device_count))
     return local_rank
@@ -374,9 +385,10 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
-    elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], device)
-    per_rank_own = gather_ranks(torch, dist, 1e3 * own_elapsed / steps, device)
-    per_rank_ev = gather_ranks(torch, dist, ev_ms / steps, device)
+    rdev = ctx.get("reduce_device", device)
+    elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], rdev)
+    per_rank_own = gather_ranks(torch, dist, 1e3 * own_elapsed / steps, rdev)
+    per_rank_ev = gather_ranks(torch, dist, ev_ms / steps, rdev)
     ev_ms = ev_ms_max
 
     result = None
@@ -654,7 +666,7 @@ def main(argv=None):
     local_rank = device_for_rank(int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist, world, rank = init_distributed(torch, "nccl", device)
+    dist, world, rank = init_distributed(torch, "gloo" if rehearsal() else "nccl", device)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
@@ -689,6 +701,9 @@ def main(argv=None):
         result["extra_workloads"] = extras
 
     rc = 0
+    if rank == 0 and rehearsal():
+        result["rehearsal"] = ("RTLWS_BENCH_REHEARSAL=1: %d ranks share %d device(s) over gloo -- the N-rank code path, "
+                               "not a measurement" % (world, torch.cuda.device_count()))
     if rank == 0:
         # A parity block that is non-finite or over its bound is a FAILED run: the line is still
         # printed (strict JSON: a non-finite number becomes a string), the exit code says so.

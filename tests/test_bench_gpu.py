@@ -97,3 +97,28 @@ def test_launch_on_hip_default_stream_is_ordered_with_torch(built, oracle):
         rel = np.abs(got[:64] - ref) / np.maximum(ref, 1e-5 * ref.max(axis=1, keepdims=True))
         assert rel.max() <= 1e-4
     eng.close()
+
+
+def test_two_ranks_rehearsal_on_one_gpu():
+    """The N-rank path of bench.py with the real GPU steps, on a box with ONE GPU: two ranks under
+    torch.distributed.run share device 0 and rendezvous over gloo (RTLWS_BENCH_REHEARSAL=1; RCCL
+    refuses two ranks on one device).  What is checked is the code path the driver's 8-GPU run
+    takes -- one line from rank 0, n_gpus = 2, both ranks' own times, the whole-job value = 2 x
+    frames x steps / elapsed, parity of what rank 0 timed -- not the numbers."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RTLWS_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "40", "--warmup", "10", "--frames", "8192"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "rehearsal" in r and "cpu_baseline" not in r and "extra_workloads" not in r
+    assert abs(r["value"] - 2 * 40 * 8192 / (r["ms_per_step"] * 40e-3)) / r["value"] < 1e-9
+    pr = r["per_rank"]
+    assert len(pr["ms_per_step_own"]["all"]) == 2 and len(pr["event_ms_per_step"]["all"]) == 2
+    assert pr["ms_per_step_own"]["max"] <= r["ms_per_step"] * 1.001
+    assert "failed" not in r["parity"] and r["scaling"] == "weak"

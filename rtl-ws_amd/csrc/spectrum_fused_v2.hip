@@ -5,17 +5,19 @@
 // spectrum_fused.hip (whose "virtual thread" vt = 2t + h is one of that kernel's N/16
 // threads), so results are bit-identical to it.
 //
-// Why (VERDICT r2 "next" #2, DESIGN.md §6 configs[2]): the 256-thread form spends
-// half of a frame's cycles not issuing vector instructions -- four wavefronts meet at
-// four __syncthreads() per frame and a single wavefront can use at most every other
-// issue slot of its SIMD.  Here
-//   * a barrier joins two wavefronts instead of four, and there are half as many
-//     LDS instructions: every access is 16 bytes (the two virtual threads of a lane
+// Why: the N/16-thread form at these sizes joins two or four wavefronts at four
+// __syncthreads() per frame, and a single wavefront can use at most every other issue slot
+// of its SIMD.  Here
+//   * a barrier joins half as many wavefronts (none at N = 2048), and there are half as
+//     many LDS instructions: every access is 16 bytes (the two virtual threads of a lane
 //     are adjacent in every index the transpositions use);
 //   * each lane carries two independent radix-16 chains per pass;
 //   * the 256-VGPR budget of 2 wavefronts per SIMD has room for the one-frame-ahead
-//     prefetch of the raw bytes (sixteen 4-byte loads per lane) next to the window
-//     weights and the K-frame accumulators, which the 168-VGPR build had to drop.
+//     prefetch of the raw bytes (sixteen 4-byte loads per lane).
+// What that buys, measured: +5..8 % on K = 1 rows (rect_4096pt 0.53 ->
+// 0.58, rect_2048pt 0.58 -> 0.61 of the HBM roofline) and nothing on K = 8 rows, which are
+// bound by the energy of the transform at the package power cap, not by its schedule
+// (§6.3) -- so the shim sends K = 1 descriptors here and keeps K > 1 on spectrum_fused.hip.
 //
 // Reference semantics: src/spectrum.c:47-63 (convert), :21 (forward DFT), :23-34
 // (|X|^2, fft-shift, accumulate, DC-slot rule); the K loop of src/cbb_main.c:50-59;

@@ -93,6 +93,15 @@ def test_bad_open_arguments(built):
     d = built.make_desc(1024)
     assert not L.rtlws_stream_open(0, C.byref(d), 128, 1, cb, None)       # needs >= 2 slots
     assert not L.rtlws_stream_open(0, C.byref(d), 0, 3, cb, None)
+    # rtlws_stream_open_q: 1 <= queues <= min(ring_slots, 8)
+    L.rtlws_stream_open_q.argtypes = [C.c_int, C.POINTER(built.SpectraDesc), C.c_long, C.c_int, C.c_int, CB, C.c_void_p]
+    L.rtlws_stream_open_q.restype = C.c_void_p
+    assert not L.rtlws_stream_open_q(0, C.byref(d), 128, 3, 0, cb, None)
+    assert not L.rtlws_stream_open_q(0, C.byref(d), 128, 3, 4, cb, None)     # more queues than slots
+    assert not L.rtlws_stream_open_q(0, C.byref(d), 128, 12, 9, cb, None)
+    h = L.rtlws_stream_open_q(0, C.byref(d), 128, 3, 3, cb, None)
+    assert h
+    L.rtlws_stream_close(h)
 
 
 def test_multi_stream_driver_realtime_no_drops(built):

@@ -25,12 +25,16 @@ eng = rtlws.Engine(0)
 t0 = time.time()
 n_cases, worst, bytes_checked = 0, 0.0, 0
 while time.time() - t0 < budget_s:
-    if rng.random() < 0.5:
+    u = rng.random()
+    fused_size = u < 0.35
+    if fused_size:
+        N = int(rng.choice([1024, 2048, 4096]))               # spectrum_f64_fused.hip (cmplx_u8, no CIC)
+    elif u < 0.65:
         N = int(2 ** rng.integers(1, 14))                     # 2 .. 8192
     else:
         N = int(rng.integers(2, 1500))                        # direct-sum sizes, primes included
     K = int(rng.choice([1, 1, 2, 3, 6, 8]))
-    rows = int(rng.integers(1, 4))
+    rows = int(rng.integers(1, 40)) if fused_size else int(rng.integers(1, 4))
     window = str(rng.choice(["rect", "rect", "hann"]))
     out = str(rng.choice(["power_sum", "power_sum", "mean_db", "payload_u8"]))
     gain = int(rng.choice([0, 15, -25, 40, -9, 9]))

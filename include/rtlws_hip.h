@@ -182,8 +182,12 @@ int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int cou
  * reference-API paths -- spectrum_add_* (spectrum.h) and cbb_main.h -- move
  * one to six frames per call, so they go through this entry point: same
  * descriptor, same semantics and frame layout as rtlws_spectra_batch, f64
- * arithmetic, any 2 <= n_fft <= 8192 (radix-2 in LDS for powers of two, the
- * direct sum otherwise), one workgroup per output row.
+ * arithmetic, any 2 <= n_fft <= 8192.  1024- / 2048- / 4096-point cmplx_u8 frames
+ * without CIC run the fused throughput kernel (spectrum_f64_fused.hip: 4.85e8
+ * 1024-point spectra/s on one MI355X, 0.62 of the HBM roofline at 2N + 8N/K bytes
+ * per frame; needs d_out 16-byte aligned, else the general kernel is used); everything
+ * else one workgroup per output row (radix-2 in LDS for powers of two, the direct sum
+ * otherwise).
  *   RTLWS_OUT_POWER_SUM / RTLWS_OUT_MEAN_DB : d_out rows of n_fft doubles
  *   RTLWS_OUT_PAYLOAD_U8                    : d_out rows of n_fft bytes,
  *       clamp((int)(10*log10(fabs(g*sum/K))), 0, 255) evaluated in double

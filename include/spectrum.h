@@ -23,8 +23,8 @@
  *
  * Differences, stated so a maintainer is not surprised:
  *   - 2 <= N <= 8192 (a frame lives in the 160 KiB LDS of one compute unit as
- *     complex doubles): radix-2 for powers of two, a direct O(N^2) sum for any
- *     other N.  There is no CPU path: if no HIP device is usable, or N is out of
+ *     complex doubles): the fused radix-16 kernel at N = 1024 / 2048 / 4096, radix-2
+ *     for the other powers of two, a direct O(N^2) sum for any other N.  There is no CPU path: if no HIP device is usable, or N is out of
  *     range, spectrum_alloc returns NULL (the reference never reports failure).
  *   - Arithmetic is f64 on the device, like the reference (f64 via FFTW):
  *     increments agree with an f64 FFT to <= 1e-10 relative per bin under the

@@ -158,6 +158,11 @@ rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, lo
     s->cb = cb;
     s->user = user;
     s->slots = (struct slot*)calloc((size_t)ring_slots, sizeof(struct slot));
+    if (!s->slots) {
+        rtlws_engine_destroy(s->eng);
+        free(s);
+        return NULL;
+    }
     pthread_mutex_init(&s->mu, NULL);
     pthread_cond_init(&s->cv_work, NULL);
     pthread_cond_init(&s->cv_free, NULL);

@@ -10,7 +10,9 @@
  * chunk stay at four (copy, launch, copy, record).  Results are delivered in push order
  * whatever order the queues finish in (the worker walks the ring).
  *
- * How many queues (measured, one MI355X, 128-frame chunks, profiles/r03_multi_stream.jsonl):
+ * How many queues (measured with rows copied back by the copy engine, one MI355X, 128-frame
+ * chunks, profiles/r03_multi_stream_experiments.txt; the kernel now stores rows into the pinned
+ * slot itself, see rtlws_stream_open_q):
  *   one sensor on the device      1 queue 2.5e6 spectra/s, 4 queues 4.7e6 (+88 %)
  *   four / eight sensors          1 queue EACH 6.9e6 / 5.9e6; 4 each 5.5e6 / 3.8e6 (32 HIP
  *                                 streams oversubscribe the hardware queues); a shared pool of
@@ -43,6 +45,8 @@ struct slot {
 
 struct rtlws_stream {
     rtlws_engine* eng;
+    int zero_copy_out;               /* the kernel stores its rows straight into the pinned host slot */
+    int zero_copy_in;                /* experiment: the kernel reads the pinned host slot itself */
     int nq;                          /* dedicated queues of this stream (0: the engine's own) */
     void* q[8];
     rtlws_spectra_desc desc;
@@ -166,6 +170,19 @@ rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, lo
     pthread_mutex_init(&s->mu, NULL);
     pthread_cond_init(&s->cv_work, NULL);
     pthread_cond_init(&s->cv_free, NULL);
+    {
+        /* Rows written by the kernel itself into pinned (device-mapped) host memory -- no D2H copy,
+         * one HIP call fewer per chunk, and the copy engine out of the way of the H2D copies:
+         * one sensor 4.8e6 -> 6.9e6 spectra/s, eight on one device 5.8e6 -> 9.1e6, byte-payload rows
+         * 1.85e7 -> 2.2e7 (profiles/r03_multi_stream.jsonl).  RTLWS_STREAM_ZEROCOPY_OUT=0 stages the
+         * rows in device memory and copies them (A/B).  Reading the INPUT from the pinned slot the
+         * same way (RTLWS_STREAM_ZEROCOPY_IN=1) helps one sensor (+22 %) and costs 27 % where the
+         * H2D link is the limit (the copy engine moves 45 GB/s, the kernel's 2-byte loads 32): off. */
+        const char* z = getenv("RTLWS_STREAM_ZEROCOPY_OUT");
+        s->zero_copy_out = !(z && z[0] == '0');
+        z = getenv("RTLWS_STREAM_ZEROCOPY_IN");
+        s->zero_copy_in = (z && z[0] == '1');
+    }
     if (queues > 1) {                 /* 1: the engine's own queue, as before */
         for (i = 0; i < queues; i++) {
             s->q[i] = rtlws_queue_create(s->eng);
@@ -215,9 +232,10 @@ int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block)
     sl->t_push_ms = now_ms();
     memcpy(sl->h_in, iq_host, s->in_bytes);
     /* copy in, transform, copy out, mark: in program order on this slot's queue */
-    if (rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, sl->q) ||
-        rtlws_spectra_batch(s->eng, &s->desc, sl->d_in, s->frames_per_chunk, sl->d_out, sl->q) ||
-        rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, sl->q) ||
+    if ((!s->zero_copy_in && rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, sl->q)) ||
+        rtlws_spectra_batch(s->eng, &s->desc, s->zero_copy_in ? sl->h_in : sl->d_in, s->frames_per_chunk,
+                            s->zero_copy_out ? sl->h_out : sl->d_out, sl->q) ||
+        (!s->zero_copy_out && rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, sl->q)) ||
         rtlws_event_record(sl->done, s->eng, sl->q)) {
         /* part of the chain may already be queued against this slot's buffers, and
          * the slot stays FREE: drain the queue so that the next push cannot

@@ -137,13 +137,17 @@ def test_bench_realtime_workload_reports_per_device(built):
     assert 0.9 * 8 * 2343.75 < r["value"] < 1.1 * 8 * 2343.75
 
 
-@pytest.mark.parametrize("queues", ["3", "1"])
-def test_stream_queue_per_slot_and_one_queue_give_the_same_rows(built, oracle, queues):
-    """One in-order queue per ring slot (consecutive chunks overlap) and the one-queue form
-    deliver the same rows, in push order, for payload output as well."""
+@pytest.mark.parametrize("queues,zc_out,zc_in", [("3", "1", "0"), ("1", "1", "0"), ("3", "0", "0"), ("2", "1", "1")])
+def test_stream_queue_per_slot_and_one_queue_give_the_same_rows(built, oracle, queues, zc_out, zc_in):
+    """Every transport form delivers the same rows, in push order, for payload output as well:
+    consecutive chunks on different queues or all on one; rows stored by the kernel straight into
+    the pinned host slot (the default) or staged in device memory and copied; input copied to the
+    device (the default) or read by the kernel from the pinned slot."""
     import ctypes as C
     from rtlws import synth
     os.environ["RTLWS_STREAM_QUEUES"] = queues
+    os.environ["RTLWS_STREAM_ZEROCOPY_OUT"] = zc_out
+    os.environ["RTLWS_STREAM_ZEROCOPY_IN"] = zc_in
     try:
         L = built.amd_lib()
         L.rtlws_stream_open.restype = C.c_void_p
@@ -167,7 +171,8 @@ def test_stream_queue_per_slot_and_one_queue_give_the_same_rows(built, oracle, q
         L.rtlws_stream_flush(h)
         L.rtlws_stream_close(h)
     finally:
-        os.environ.pop("RTLWS_STREAM_QUEUES", None)
+        for k in ("RTLWS_STREAM_QUEUES", "RTLWS_STREAM_ZEROCOPY_OUT", "RTLWS_STREAM_ZEROCOPY_IN"):
+            os.environ.pop(k, None)
     assert [f for f, _ in got] == [64 * c for c in range(12)]
     rows = np.concatenate([r for _, r in got])
     ref = oracle.batch_spectra_u8(iq, 1024, K=2, nthreads=4)

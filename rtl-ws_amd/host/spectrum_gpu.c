@@ -27,6 +27,7 @@ struct spectrum {
     double* d_out;    /* N doubles */
     void* h_in;       /* pinned */
     double* h_out;    /* pinned */
+    int zero_copy;
 };
 
 struct spectrum* spectrum_alloc(int N)
@@ -53,6 +54,10 @@ struct spectrum* spectrum_alloc(int N)
     s->d_out = (double*)rtlws_dev_alloc(s->eng, (size_t)N * sizeof(double));
     s->h_in = rtlws_pinned_alloc((size_t)N * sizeof(cmplx_s32));
     s->h_out = (double*)rtlws_pinned_alloc((size_t)N * sizeof(double));
+    {
+        const char* z = getenv("RTLWS_DROPIN_ZEROCOPY");
+        s->zero_copy = !(z && z[0] == '0');
+    }
     if (!s->d_in || !s->d_out || !s->h_in || !s->h_out) {
         fprintf(stderr, "rtlws: spectrum_alloc: %s\n", rtlws_last_error());
         spectrum_free(s);
@@ -80,10 +85,15 @@ static int add_frame(struct spectrum* s, const void* src, size_t sample_bytes, i
     d.output = RTLWS_OUT_POWER_SUM;
 
     memcpy(s->h_in, src, (size_t)N * sample_bytes);
-    if (rtlws_copy_h2d(s->eng, s->d_in, s->h_in, (size_t)N * sample_bytes, NULL) ||
-        rtlws_spectra_batch_f64(s->eng, &d, s->d_in, 1, s->d_out, NULL) ||
-        rtlws_copy_d2h(s->eng, s->h_out, s->d_out, (size_t)N * sizeof(double), NULL) ||
-        rtlws_stream_sync(s->eng, NULL)) {
+    /* One frame per call: the kernel reads the frame from, and stores the row into, the pinned
+     * (device-mapped) staging buffers itself -- one launch and one synchronisation per call
+     * instead of two copies around them (RTLWS_DROPIN_ZEROCOPY=0: the copies; A/B). */
+    if (s->zero_copy
+            ? (rtlws_spectra_batch_f64(s->eng, &d, s->h_in, 1, s->h_out, NULL) || rtlws_stream_sync(s->eng, NULL))
+            : (rtlws_copy_h2d(s->eng, s->d_in, s->h_in, (size_t)N * sample_bytes, NULL) ||
+               rtlws_spectra_batch_f64(s->eng, &d, s->d_in, 1, s->d_out, NULL) ||
+               rtlws_copy_d2h(s->eng, s->h_out, s->d_out, (size_t)N * sizeof(double), NULL) ||
+               rtlws_stream_sync(s->eng, NULL))) {
         fprintf(stderr, "rtlws: spectrum_add: device failure: %s\n", rtlws_last_error());
         return -3;
     }

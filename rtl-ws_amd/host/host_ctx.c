@@ -18,6 +18,15 @@ static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static struct rtlws_host_ctx g_ctx;
 static int g_tried = 0;
 
+/* The drop-in entry points hand over host buffers: by default the kernels read and write the
+ * pinned (device-mapped) staging buffers themselves -- one launch and one synchronisation per
+ * call; RTLWS_DROPIN_ZEROCOPY=0 puts an H2D and a D2H copy around the launch instead (A/B). */
+static int zero_copy(void)
+{
+    const char* z = getenv("RTLWS_DROPIN_ZEROCOPY");
+    return !(z && z[0] == '0');
+}
+
 int rtlws_host_device(void)
 {
     const char* s = getenv("RTLWS_DEVICE");
@@ -86,10 +95,12 @@ int rtlws_host_cic(int R, const cmplx_u8* src, int src_len, cmplx_s32* dst, int 
         rc = -3;
     } else {
         memcpy(c->h_in, src, in_bytes);
-        if (rtlws_copy_h2d(c->eng, c->d_in, c->h_in, in_bytes, NULL) ||
-            rtlws_cic_block_sums(c->eng, R, c->d_in, dst_len, c->d_out, NULL) ||
-            rtlws_copy_d2h(c->eng, c->h_out, c->d_out, out_bytes, NULL) ||
-            rtlws_stream_sync(c->eng, NULL))
+        if (zero_copy()
+                ? (rtlws_cic_block_sums(c->eng, R, c->h_in, dst_len, c->h_out, NULL) || rtlws_stream_sync(c->eng, NULL))
+                : (rtlws_copy_h2d(c->eng, c->d_in, c->h_in, in_bytes, NULL) ||
+                   rtlws_cic_block_sums(c->eng, R, c->d_in, dst_len, c->d_out, NULL) ||
+                   rtlws_copy_d2h(c->eng, c->h_out, c->d_out, out_bytes, NULL) ||
+                   rtlws_stream_sync(c->eng, NULL)))
             rc = -3;
         else
             memcpy(dst, c->h_out, out_bytes);
@@ -145,10 +156,12 @@ void halfband_decimate(const float* input, float* output, int output_len, float*
         /* [10 history samples | 2*output_len new samples] */
         memcpy(stage, delay, (HALF_BAND_N - 1) * sizeof(float));
         memcpy(stage + (HALF_BAND_N - 1), input, n_in * sizeof(float));
-        if (rtlws_copy_h2d(c->eng, c->d_in, stage, in_bytes, NULL) ||
-            rtlws_halfband(c->eng, (const float*)c->d_in, (float*)c->d_out, output_len, NULL) ||
-            rtlws_copy_d2h(c->eng, c->h_out, c->d_out, out_bytes, NULL) ||
-            rtlws_stream_sync(c->eng, NULL))
+        if (zero_copy()
+                ? (rtlws_halfband(c->eng, stage, (float*)c->h_out, output_len, NULL) || rtlws_stream_sync(c->eng, NULL))
+                : (rtlws_copy_h2d(c->eng, c->d_in, stage, in_bytes, NULL) ||
+                   rtlws_halfband(c->eng, (const float*)c->d_in, (float*)c->d_out, output_len, NULL) ||
+                   rtlws_copy_d2h(c->eng, c->h_out, c->d_out, out_bytes, NULL) ||
+                   rtlws_stream_sync(c->eng, NULL)))
             rc = -3;
         else {
             memcpy(output, c->h_out, out_bytes);

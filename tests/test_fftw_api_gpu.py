@@ -82,3 +82,113 @@ def test_spectrum_stage_over_the_fftw_api_equals_the_oracle(fftw_api, oracle):
     for f in range(K):
         assert oracle.spectrum_add_cmplx_u8(N, iq[f], ref) == 0
     assert np.abs(ps - ref).max() <= 1e-12 * ref.max()
+
+
+def test_config2_full_size_every_bin_of_every_row_against_the_fftw_api(fftw_api, engine):
+    """BASELINE.json configs[1] at its full size -- 65 536 frames of 1024 cmplx_u8 -- with EVERY bin
+    of EVERY row compared (tests/test_fullsize_gpu.py checks every row through Parseval and a
+    768-row subsample against the oracle): the reference's call sequence, fftw_execute once per frame
+    on the converted frame (src/spectrum.c:54-60,21), through the FFTW3-API library of the image,
+    then src/spectrum.c:23-34's |X|^2 / shift / DC-slot rule in numpy.  The f64 batch kernel must
+    agree under the strict metric (floor 1e-9 of the row maximum, 1e-10), the f32 batch kernel within
+    its stated budget (1e-4 within 50 dB of the row maximum)."""
+    nframes, N = 65536, 1024
+    rng = np.random.default_rng(77)
+    iq = rng.integers(0, 256, size=(nframes, N, 2), dtype=np.uint8)
+    n = np.arange(N)
+    for f in range(0, nframes, 97):                      # tone + noise frames among the random ones
+        ph = 2 * np.pi * ((f * 7) % N) * n / N
+        iq[f, :, 0] = np.clip(np.round(77 * np.cos(ph) + 128 + rng.normal(0, 6, N)), 0, 255)
+        iq[f, :, 1] = np.clip(np.round(77 * np.sin(ph) + 128 + rng.normal(0, 6, N)), 0, 255)
+    got32 = engine.spectra(iq, N)
+    got64 = engine.spectra(iq, N, f64=True)
+
+    L = fftw_api
+    L.fftw_execute_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    x0 = np.zeros(N, dtype=np.complex128)
+    y0 = np.zeros(N, dtype=np.complex128)
+    plan = L.fftw_plan_dft_1d(N, x0.ctypes.data_as(C.c_void_p), y0.ctypes.data_as(C.c_void_p), FFTW_FORWARD, FFTW_ESTIMATE)
+    assert plan
+    worst32 = worst64 = 0.0
+    chunk = 4096
+    for a in range(0, nframes, chunk):
+        x = ((iq[a:a + chunk].astype(np.float64) - 128.0) / 128.0).view(np.complex128).reshape(-1, N)
+        x = np.ascontiguousarray(x)
+        X = np.empty_like(x)
+        for r in range(x.shape[0]):                      # one fftw_execute per frame, as the reference does
+            L.fftw_execute_dft(plan, x[r].ctypes.data_as(C.c_void_p), X[r].ctypes.data_as(C.c_void_p))
+        P = X.real ** 2 + X.imag ** 2
+        ref = np.roll(P, N // 2, axis=1)                 # slot i shows bin (i + N/2) % N
+        ref[:, N // 2] = ref[:, N // 2 - 1]              # K = 1: the DC slot repeats its left neighbour
+        mx = ref.max(axis=1, keepdims=True)
+        worst64 = max(worst64, float((np.abs(got64[a:a + chunk] - ref) / np.maximum(ref, 1e-9 * mx)).max()))
+        worst32 = max(worst32, float((np.abs(got32[a:a + chunk].astype(np.float64) - ref) / np.maximum(ref, 1e-5 * mx)).max()))
+    L.fftw_destroy_plan(plan)
+    assert worst64 <= 1e-10, worst64
+    assert worst32 <= 1e-4, worst32
+
+
+def _fftw_rows(L, x):
+    """fftw_execute_dft once per row of x (complex128, C-contiguous) through one plan."""
+    n = x.shape[1]
+    L.fftw_execute_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    a = np.zeros(n, dtype=np.complex128)
+    b = np.zeros(n, dtype=np.complex128)
+    plan = L.fftw_plan_dft_1d(n, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), FFTW_FORWARD, FFTW_ESTIMATE)
+    assert plan
+    X = np.empty_like(x)
+    for r in range(x.shape[0]):
+        L.fftw_execute_dft(plan, x[r].ctypes.data_as(C.c_void_p), X[r].ctypes.data_as(C.c_void_p))
+    L.fftw_destroy_plan(plan)
+    return X
+
+
+def test_config3_full_size_against_the_fftw_api(fftw_api, engine):
+    """configs[2] at full size (16 384 frames of 4096, periodic Hann, K = 8, mean dB), every bin of
+    every row: window and conversion in numpy, the transform through the FFTW3 API, then the
+    reference's accumulation with its DC-slot weights (slot N/2 = sum_k (K-k) P_k[N-1]) and
+    10*log10(sum / K).  f32 kernel <= 2e-4 dB, f64 kernel <= 1e-9 dB."""
+    from rtlws import synth
+    nframes, N, K = 16384, 4096, 8
+    iq = synth.tone_noise_iq(nframes, N, seed=404)
+    got32 = engine.spectra(iq, N, k_avg=K, window="hann", output="mean_db").astype(np.float64)
+    got64 = engine.spectra(iq, N, k_avg=K, window="hann", output="mean_db", f64=True)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)
+    worst32 = worst64 = 0.0
+    chunk = 256 * K
+    for a in range(0, nframes, chunk):
+        x = (iq[a:a + chunk].astype(np.float64) - 128.0) / 128.0 * w[None, :, None]
+        X = _fftw_rows(fftw_api, np.ascontiguousarray(x).view(np.complex128).reshape(-1, N))
+        P = (X.real ** 2 + X.imag ** 2).reshape(-1, K, N)
+        ref = np.roll(P.sum(axis=1), N // 2, axis=1)
+        wk = (K - np.arange(K))[None, :]
+        ref[:, N // 2] = (wk * P[:, :, N - 1]).sum(axis=1)
+        ref_db = 10 * np.log10(ref / K)
+        r0 = a // K
+        worst32 = max(worst32, float(np.abs(got32[r0:r0 + ref.shape[0]] - ref_db).max()))
+        worst64 = max(worst64, float(np.abs(got64[r0:r0 + ref.shape[0]] - ref_db).max()))
+    assert worst64 <= 1e-9, worst64
+    assert worst32 <= 2e-4, worst32
+
+
+def test_config4_full_size_against_the_fftw_api(fftw_api, engine):
+    """configs[3] at full size (8 192 spectra of 2048 points from 16 384 raw IQ samples each, CIC
+    8:1 fused): the block sums of (x - 128) in numpy integers (src/resample.c:24-25,35), /128
+    (src/spectrum.c:74-75), the transform through the FFTW3 API; every bin of every row within the
+    f32 budget."""
+    from rtlws import synth
+    nspec, N, R = 8192, 2048, 8
+    iq = synth.tone_noise_iq(nspec, N * R, seed=505)
+    got = engine.spectra(iq, N, cic_r=R).astype(np.float64)
+    worst = 0.0
+    chunk = 1024
+    for a in range(0, nspec, chunk):
+        s = (iq[a:a + chunk].astype(np.int32) - 128).reshape(-1, N, R, 2).sum(axis=2)
+        x = (s.astype(np.float64) / 128.0)
+        X = _fftw_rows(fftw_api, np.ascontiguousarray(x).view(np.complex128).reshape(-1, N))
+        P = X.real ** 2 + X.imag ** 2
+        ref = np.roll(P, N // 2, axis=1)
+        ref[:, N // 2] = ref[:, N // 2 - 1]
+        mx = ref.max(axis=1, keepdims=True)
+        worst = max(worst, float((np.abs(got[a:a + chunk] - ref) / np.maximum(ref, 1e-5 * mx)).max()))
+    assert worst <= 1e-4, worst

@@ -119,3 +119,30 @@ def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
     # 8e7 issue cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
     assert abs(out["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.0e9)) < 1e-12
     assert bench.valu_issue_frac("other", 80e-6, 256) is None
+
+
+def test_parity_block_single_frame_db_rows_are_bounded_within_50_db(oracle):
+    """K = 1 dB rows of the f32 kernel: the bound applies to bins within 50 dB of the row maximum
+    (DESIGN.md §5); an error placed on a weak bin is reported under `all_bins` and does not fail,
+    the same error on a strong bin does."""
+    import bench
+    from rtlws import synth
+    wl = (1024, 1, "rect", "mean_db", 0, 4)
+    iq = synth.pure_tone_iq(4, 1024, seed=1)
+    ref = oracle.batch_spectra_u8(iq, 1024)
+    db = (10 * np.log10(ref)).astype(np.float32)
+    weak = int(np.argmin(ref[0]))
+    strong = int(np.argmax(ref[0]))
+    assert ref[0, weak] < 1e-5 * ref[0, strong]
+    bad_weak = db.copy()
+    bad_weak[0, weak] += 0.01
+    out = bench.parity_block(np, oracle, wl, iq, bad_weak, 4)
+    assert out["max_abs_db_err_all_bins"] > 5e-3 and out["max_abs_db_err_within_50db"] < 1e-4
+    assert bench.parity_failures(out) == []
+    bad_strong = db.copy()
+    bad_strong[0, strong] += 0.01
+    out = bench.parity_block(np, oracle, wl, iq, bad_strong, 4)
+    assert bench.parity_failures(out) == ["max_abs_db_err_within_50db"]
+    # f64 rows are bounded on every bin
+    out = bench.parity_block(np, oracle, wl, iq, 10 * np.log10(ref), 4, f64=True)
+    assert out["max_abs_db_err"] < 1e-12

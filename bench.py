@@ -70,12 +70,33 @@ WORKLOADS = {
     "hann_4096pt_k8_db_f64": (4096, 8, "hann", "mean_db", 0, 16384),
     "rect_2048pt_f64": (2048, 1, "rect", "power_sum", 0, 32768),
     "rect_4096pt_f64": (4096, 1, "rect", "power_sum", 0, 16384),
+    # configs[3] in the reference's precision (src/resample.c:21-40 -> src/spectrum.c:65-81, all
+    # double): 2*8*2048 + 8*2048 = 49 152 B per spectrum; and the reference's own factor
+    "cic8_2048pt_f64": (2048, 1, "rect", "power_sum", 8, 8192),
+    "cic12_2048pt_f64": (2048, 1, "rect", "power_sum", 12, 5456),
+    # f64 ARITHMETIC, f32 ROWS (RTLWS_FLAG_ROWS_F32): the contract's own byte count -- 6 144 B per
+    # 1024-point spectrum, SURVEY.md 8d -- with the reference's arithmetic: the strict metric
+    # (floor 1e-9) is one f32 rounding, no builder-chosen floor
+    "batched_1024pt_64k_frames_f64c_f32o": (1024, 1, "rect", "power_sum", 0, 65536),
+    "hann_4096pt_k8_db_f64c_f32o": (4096, 8, "hann", "mean_db", 0, 16384),
+    "cic8_2048pt_f64c_f32o": (2048, 1, "rect", "power_sum", 8, 8192),
 }
-F64_WORKLOADS = ("batched_1024pt_64k_frames_f64", "hann_4096pt_k8_db_f64", "rect_2048pt_f64", "rect_4096pt_f64")
+F64_WORKLOADS = ("batched_1024pt_64k_frames_f64", "hann_4096pt_k8_db_f64", "rect_2048pt_f64", "rect_4096pt_f64",
+                 "cic8_2048pt_f64", "cic12_2048pt_f64")
+F64C_F32O_WORKLOADS = ("batched_1024pt_64k_frames_f64c_f32o", "hann_4096pt_k8_db_f64c_f32o", "cic8_2048pt_f64c_f32o")
 HEADLINE = "batched_1024pt_64k_frames"
-# configs[2], configs[3] and the reference's own decimation factor ride along on the default line
-EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", "batched_1024pt_64k_frames_f64")
+# configs[2], configs[3] and the reference's own decimation factor ride along on the default line,
+# then configs[1] and configs[3] in the reference's arithmetic (f64 rows; f32 rows)
+EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", "batched_1024pt_64k_frames_f64",
+                   "batched_1024pt_64k_frames_f64c_f32o", "cic8_2048pt_f64")
+# ... and these carry their own cpu_baseline (the BASELINE.json configurations other than the headline)
+EXTRA_CPU_BASELINE = {"hann_4096pt_k8_db": 0.2, "cic8_2048pt": 0.2}      # name -> budget_scale
 EXTRA_STEPS = 200
+
+
+def precision_of(name):
+    """"f32" | "f64" | "f64c_f32o" (f64 arithmetic, rows rounded once to f32)."""
+    return "f64" if name in F64_WORKLOADS else "f64c_f32o" if name in F64C_F32O_WORKLOADS else "f32"
 
 
 def algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output="power_sum", f64=False):
@@ -231,6 +252,7 @@ def fan_out(gpus, argv, plumbing_cpu=False):
 # ---- one workload: settle, time K steps, price against HBM --------------------
 
 def parity_block(np, po, wl, host_in, got, nchk, f64=False):
+    """f64: the rows come from f64 ARITHMETIC (f64 or f32 rows): no relaxed-floor statistics."""
     n_fft, k_avg, window, output, cic_r, _ = wl
     if output == "cs32":
         want = (host_in.astype(np.int32) - 128).reshape(-1, cic_r, 2).sum(axis=1).reshape(nchk, -1)
@@ -283,6 +305,13 @@ def parity_block(np, po, wl, host_in, got, nchk, f64=False):
 PARITY_BOUNDS = {"max_rel_err_floor1e-5": 1e-4, "max_rel_err_floor1e-9": 5e-3, "p99.9_rel_err_floor1e-9": 1e-4,
                  "max_abs_db_err": 2e-4, "max_abs_db_err_within_50db": 4.4e-4, "max_byte_diff": 1}
 PARITY_BOUNDS_F64 = {"max_rel_err_floor1e-9": 1e-10, "max_abs_db_err": 1e-9}
+# f64 arithmetic, f32 rows: one f32 rounding (2^-24 relative; an f32 ulp of a ~100 dB value)
+PARITY_BOUNDS_F64C_F32O = {"max_rel_err_floor1e-9": 6.0e-8, "max_rel_err_floor1e-5": 6.0e-8,
+                           "p99.9_rel_err_floor1e-9": 6.0e-8, "max_abs_db_err": 1e-5}
+
+
+def parity_bounds_for(name):
+    return {"f64": PARITY_BOUNDS_F64, "f64c_f32o": PARITY_BOUNDS_F64C_F32O}.get(precision_of(name))
 
 
 def parity_failures(block, bounds=None):
@@ -312,7 +341,7 @@ def gather_ranks(torch, dist, value, device=None):
     return [float(x[0]) for x in out]
 
 
-def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False):
+def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0):
     """Allocate `sets` rotating buffer sets, run max(warmup, SETTLE_LAUNCHES)
     untimed launches, time exactly `steps` launches between barrier +
     synchronise on both sides (wall clock -> value) and between HIP events on
@@ -330,12 +359,15 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     dist, world, rank, device = ctx["dist"], ctx["world"], ctx["rank"], ctx["device"]
     wl = WORKLOADS[name]
     n_fft, k_avg, window, output, cic_r, frames = wl
-    f64 = name in F64_WORKLOADS
+    prec = precision_of(name)
+    f64 = prec != "f32"                    # f64 arithmetic (rtlws_spectra_batch_f64)
+    rows64 = prec == "f64"                 # ... with f64 rows
     if frames_override > 0:
         frames = frames_override - frames_override % k_avg
     spf = n_fft * max(cic_r, 1)
     cic_only = (output == "cs32")
-    desc = None if cic_only else rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0)
+    desc = None if cic_only else rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0,
+                                                 rtlws.FLAG_ROWS_F32 if prec == "f64c_f32o" else 0)
     rows = frames // k_avg
 
     # device-resident inputs / outputs, allocated by torch (plumbing only)
@@ -343,7 +375,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     stream = tstream.cuda_stream
     assert stream != 0, "bench.py launches on a side stream; a zero handle would select the engine's own"
     out_dtype = torch.int32 if cic_only else (torch.uint8 if output == "payload_u8" else
-                                              (torch.float64 if f64 else torch.float32))
+                                              (torch.float64 if rows64 else torch.float32))
     out_cols = 2 * n_fft if cic_only else n_fft
     with torch.cuda.stream(tstream):
         outs = [torch.empty((rows, out_cols), dtype=out_dtype, device=device) for _ in range(sets)]
@@ -394,7 +426,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     result = None
     if rank == 0:
         value = whole_job_rate(world, steps, frames, elapsed)
-        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, f64) * frames
+        bytes_per_launch = algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, rows64) * frames
         avg_launch_s = (ev_ms / 1e3) / steps
         achieved = bytes_per_launch / avg_launch_s / 1e9
         achieved_wall = bytes_per_launch / (elapsed / steps) / 1e9
@@ -423,7 +455,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32" if cic_only else ("f64" if f64 else "f32"),      # arithmetic type of the path
+            # arithmetic type of the path (f64c_f32o: f64 arithmetic, rows rounded once to f32)
+            "dtype": "int32" if cic_only else {"f32": "f32", "f64": "f64", "f64c_f32o": "f64 arithmetic, f32 rows"}[prec],
             "data": "synthetic",
             "config": {"workload": name, "n_fft": n_fft, "frames_per_step": frames,
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
@@ -442,9 +475,13 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": 1e6 * avg_launch_s},
         }
-        vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256))
-        if vf is not None:
-            result["roofline"].update(vf)
+        # (valu_issue_frac needs the shader clock of THESE launches; a clock measured on another
+        # launch series -- profiles/valu_insts.json -- is not this run's, so the field is only
+        # emitted when the caller supplies this run's own clock: tools/inkernel_clock.py)
+        if ctx.get("sclk_ghz_this_run"):
+            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), ctx["sclk_ghz_this_run"])
+            if vf is not None:
+                result["roofline"].update(vf)
         if world > 1:
             # every rank's own figures, so a scaling loss is visible in this one line
             result["per_rank"] = {"ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
@@ -460,12 +497,12 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         host_in = ins[0][:nchk].cpu().numpy()
         got = outs[0][:nchk if cic_only else 256].cpu().numpy()
         result["parity"] = parity_block(np, po, wl, host_in, got, nchk, f64)
-        bad = parity_failures(result["parity"], PARITY_BOUNDS_F64 if f64 else None)
+        bad = parity_failures(result["parity"], parity_bounds_for(name))
         if bad:
             result["parity"]["failed"] = bad
 
         if cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_block(np, po, wl, ins[0], frames)
+            result["cpu_baseline"] = cpu_baseline_block(np, po, wl, ins[0], frames, cpu_budget_scale)
     del ins, outs
     torch.cuda.empty_cache()
     return result
@@ -476,7 +513,9 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
 # conversions, SDWA and every f64 instruction; tools/make_valu_insts.py, profiles/valu_insts.json) /
 # the SIMD-cycles this run's launch lasted (4 SIMDs per CU x CUs x launch time x the shader clock
 # rocm-smi showed under sustained load of the same workload, committed beside the count).
-def valu_issue_frac(name, avg_launch_s, cu_count):
+def valu_issue_frac(name, avg_launch_s, cu_count, sclk_ghz=None):
+    """sclk_ghz: the shader clock of the launches `avg_launch_s` was measured on (None: the
+    committed clock of another launch series -- only for offline use, never in the bench line)."""
     path = os.path.join(ROOT, "profiles", "valu_insts.json")
     try:
         rec = json.load(open(path)).get(name)
@@ -484,10 +523,13 @@ def valu_issue_frac(name, avg_launch_s, cu_count):
         rec = None
     if not rec:
         return None
-    simd_cycles = 4 * cu_count * avg_launch_s * rec["sclk_ghz_under_load"] * 1e9
+    own = sclk_ghz is not None
+    simd_cycles = 4 * cu_count * avg_launch_s * (sclk_ghz if own else rec["sclk_ghz_under_load"]) * 1e9
     return {"valu_issue_frac": rec["issue_cycles_per_launch"] / simd_cycles,
-            "valu_issue_source": "profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost, sclk under "
-                                 "load: committed measurements) / this run's launch duration"}
+            "valu_issue_source": ("profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost: committed count) / "
+                                  "this run's launch duration at this run's own shader clock (%.3f GHz)" % sclk_ghz) if own else
+                                 "profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost, sclk under "
+                                 "load: committed measurements of ANOTHER launch series) / this run's launch duration"}
 
 
 def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
@@ -504,6 +546,7 @@ def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
     sample = min(frames, max(base, 64 * cores))
     sample -= sample % k_avg
     host = dev_in[:sample].cpu().numpy()
+    win = None if window == "rect" else (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft))
 
     def timed(nthreads, nframes, budget_s, max_reps=100000):
         h = host[:nframes]
@@ -512,9 +555,12 @@ def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
         while t_cpu < budget_s and reps < max_reps:
             c0 = time.perf_counter()
             if cic_r > 1:
-                po.batch_spectra_cic_u8(h, n_fft, cic_r, K=k_avg, nthreads=nthreads, out=out)
+                po.batch_spectra_cic_u8(h, n_fft, cic_r, K=k_avg, window=win, nthreads=nthreads, out=out)
             else:
-                po.batch_spectra_u8(h, n_fft, K=k_avg, nthreads=nthreads, out=out)
+                po.batch_spectra_u8(h, n_fft, K=k_avg, window=win, nthreads=nthreads, out=out)
+            if output == "mean_db":                # the workload's epilogue belongs to the CPU path too
+                with np.errstate(divide="ignore"):
+                    np.log10(out / k_avg)
             t_cpu += time.perf_counter() - c0
             reps += 1
         return reps * nframes / t_cpu, reps
@@ -545,9 +591,10 @@ def cpu_baseline_block(np, po, wl, dev_in, frames, budget_scale=1.0):
                            "sample": "%d frames of buffer set 0, %d repetitions" % (one_n, reps1)},
             "sixteen_threads": {"value": v16, "unit": "spectra/s", "cores": min(16, cores),
                                 "sample": "%d frames of buffer set 0, %d repetitions" % (min(sample, base), reps16)},
-            "sample": "%d of the %d frames of buffer set 0, %d repetitions, f64 oracle "
+            "sample": "%d of the %d frames of buffer set 0 (%d-point%s%s, K = %d), %d repetitions, f64 oracle "
                       "(oracle/rtlws_oracle.c) on %d pthreads; one_thread: the same code on 1"
-                      % (sample, frames, repsall, cores)}
+                      % (sample, frames, n_fft, ", CIC %d:1 first" % cic_r if cic_r > 1 else "",
+                         ", Hann, mean dB" if win is not None else "", k_avg, repsall, cores)}
 
 
 REALTIME_WORKLOAD = "realtime_8x2400k"
@@ -693,11 +740,16 @@ def main(argv=None):
     if world == 1 and args.workload == HEADLINE and not args.no_extra and args.frames == 0:
         extras = []
         for name in EXTRA_WORKLOADS:
-            r = run_workload(ctx, name, EXTRA_STEPS, 0, args.sets)
-            extras.append({"workload": name, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
-                           "dtype": r["dtype"], "steps": r["steps"], "settle_launches": r["settle_launches"],
-                           "ms_per_step": r["ms_per_step"], "config": r["config"],
-                           "roofline": r["roofline"], "parity": r["parity"]})
+            with_cpu = name in EXTRA_CPU_BASELINE and not args.no_cpu_baseline
+            r = run_workload(ctx, name, EXTRA_STEPS, 0, args.sets, cpu_baseline=with_cpu,
+                             cpu_budget_scale=EXTRA_CPU_BASELINE.get(name, 1.0))
+            x = {"workload": name, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                 "dtype": r["dtype"], "steps": r["steps"], "settle_launches": r["settle_launches"],
+                 "ms_per_step": r["ms_per_step"], "config": r["config"],
+                 "roofline": r["roofline"], "parity": r["parity"]}
+            if "cpu_baseline" in r:
+                x["cpu_baseline"] = r["cpu_baseline"]
+            extras.append(x)
         result["extra_workloads"] = extras
 
     rc = 0

@@ -70,6 +70,20 @@ rtlws_engine* rtlws_engine_create(int device);
 void rtlws_engine_destroy(rtlws_engine* e);
 int rtlws_engine_device(const rtlws_engine* e);
 
+/* Kernel-selection switches, for experiments and A/B tests.  Each is read from the environment
+ * ONCE, when the engine is created (the variable in brackets), and can be changed afterwards only
+ * here -- no launch path reads the environment:
+ *   "v2"                [RTLWS_V2]                -1 default rule, 0 / 1 never / always the
+ *                                                 two-virtual-threads-per-lane f32 kernel
+ *   "blocks_per_cu"     [RTLWS_BLOCKS_PER_CU]     > 0: workgroups per CU of the f32 fused kernels
+ *   "f64_fused"         [RTLWS_F64_FUSED]         0: f64 batches on the row-per-workgroup kernel
+ *   "f64_blocks_per_cu" [RTLWS_F64_BLOCKS_PER_CU]
+ *   "cic_direct"        [RTLWS_CIC_DIRECT]        1: per-lane loads for every CIC factor but 8
+ *   "cic_round"         [RTLWS_CIC_ROUND]         1 | 2 | 4: LDS staging depth of the generic factors
+ * set: 0, or -1 for an unknown name.  get: the value ("cu_count" is readable too), -2 if unknown. */
+int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value);
+int rtlws_engine_get_option(const rtlws_engine* e, const char* name);
+
 /* Build the twiddle/window tables for an FFT size now (they are otherwise built
  * on the first rtlws_spectra_batch call, which allocates and copies and is
  * therefore not legal inside a hipGraph capture).  After this, batch launches
@@ -145,8 +159,17 @@ typedef struct rtlws_spectra_desc {
                          sample is the CIC block sum of R consecutive cmplx_u8,
                          fed as spectrum_add_cmplx_s32 would (sum/128) */
     int gain_db;      /* RTLWS_OUT_PAYLOAD_U8 only */
-    int reserved;
+    int flags;        /* RTLWS_FLAG_*; 0 = none (was `reserved`, always 0) */
 } rtlws_spectra_desc;
+
+/* rtlws_spectra_batch_f64 only: f64 ARITHMETIC, f32 ROWS.  Everything is computed in double
+ * exactly as without the flag (conversion, DFT, |X|^2, K-frame sums, DC-slot rule, dB); each
+ * output value is rounded to f32 once, on the store.  Rows are then n_fft floats -- the
+ * 2N + 4N/K bytes per frame SURVEY.md §8d prices the contract with -- and the error against
+ * the f64 reference is that one rounding (<= 6e-8 relative, any bin, any dynamic range),
+ * where the f32 transform of rtlws_spectra_batch holds 1e-4 only within 50 dB of a row's
+ * maximum.  No effect on RTLWS_OUT_PAYLOAD_U8 (bytes either way) or on rtlws_spectra_batch. */
+#define RTLWS_FLAG_ROWS_F32 1
 
 /* Precision: f32 arithmetic (inputs are exact in f32; twiddles are f64-computed and
  * rounded once).  Against an f64 evaluation: power within 1e-4 relative for every
@@ -182,16 +205,16 @@ int rtlws_payload_from_sums(rtlws_engine* e, const float* d_sums, int n, int cou
  * reference-API paths -- spectrum_add_* (spectrum.h) and cbb_main.h -- move
  * one to six frames per call, so they go through this entry point: same
  * descriptor, same semantics and frame layout as rtlws_spectra_batch, f64
- * arithmetic, any 2 <= n_fft <= 8192.  1024- / 2048- / 4096-point cmplx_u8 frames
- * without CIC run the fused throughput kernel (spectrum_f64_fused.hip: 4.85e8
- * 1024-point spectra/s on one MI355X, 0.62 of the HBM roofline at 2N + 8N/K bytes
- * per frame; needs d_out 16-byte aligned, else the general kernel is used); everything
- * else one workgroup per output row (radix-2 in LDS for powers of two, the direct sum
- * otherwise).
+ * arithmetic, any 2 <= n_fft <= 8192.  1024- / 2048- / 4096-point frames of any input
+ * kind, and cmplx_u8 through the CIC-fused input stage for cic_r = 8, 10, 12, run the
+ * fused throughput kernel (spectrum_f64_fused.hip; needs d_out -- and d_in when cic_r > 1
+ * -- 16-byte aligned, else the general kernel is used); everything else one workgroup per
+ * output row (radix-2 in LDS for powers of two, the direct sum otherwise).
  *   RTLWS_OUT_POWER_SUM / RTLWS_OUT_MEAN_DB : d_out rows of n_fft doubles
+ *       (desc->flags & RTLWS_FLAG_ROWS_F32: rows of n_fft floats, see the flag)
  *   RTLWS_OUT_PAYLOAD_U8                    : d_out rows of n_fft bytes,
  *       clamp((int)(10*log10(fabs(g*sum/K))), 0, 255) evaluated in double
- * d_in / d_out 8-byte aligned.  0 / -1 / -3. */
+ * d_in 8-byte aligned; d_out 8-byte (4-byte for f32 rows and payload bytes).  0 / -1 / -3. */
 int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* desc, const void* d_in,
                             long nframes, void* d_out, void* stream);
 

@@ -91,12 +91,27 @@ struct SpectraParamsF64 {
     const double2* tw1f;     // [64][16] scale * W_N^(t*rev16(s))
     const double2* tw2f;     // [16][2] last-pass (cos, sin/cos) pairs
     const double2* hann_csf; // [64] (0.5*cos, 0.5*sin)(2*pi*t/N)
+    int rows_f32;            // RTLWS_FLAG_ROWS_F32: f64 arithmetic, rows rounded once to f32 on the store
 };
 
-// which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip)
-constexpr bool f64_fused_kind(int n_fft, int in_kind, int cic_r)
+// which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip): the three
+// fused sizes with any input kind of spectrum.h, or cmplx_u8 through the CIC-fused input stage
+// for R = 8 and the reference's own factors 10 and 12 (in_kind: the kernels' IN_* value)
+constexpr bool f64_fused_in_kind(int in_kind)
 {
-    return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && in_kind == IN_CU8 && cic_r <= 1;
+    return in_kind == IN_CU8 || in_kind == IN_CS32 || in_kind == IN_RF32 || in_kind == IN_CU8_CIC8 ||
+           in_kind == IN_CU8_CIC10 || in_kind == IN_CU8_CIC12;
+}
+constexpr bool f64_fused_kind(int n_fft, int in_kind)
+{
+    return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && f64_fused_in_kind(in_kind);
+}
+// the last pass's (cos, tan) pairs stay in registers, except in the instantiations whose budget
+// (256 VGPRs at 2 wavefronts per SIMD) they break: those re-read them from the L2-resident 2 KiB
+// table every frame, under the LDS reads
+constexpr bool f64_fused_tw3_regs(int n_fft, int in_kind, bool win, bool kone)
+{
+    return !(n_fft == 4096 && win && !kone);
 }
 // LDS in double2 elements: 16 rows of 17*R3 (the larger of the two transpositions ends at
 // 15*17*R3 + (R3-1)*17 + 16) + one element for the DC slot of the multi-wavefront sizes
@@ -104,7 +119,9 @@ constexpr int f64_fused_lds_elems(int n_fft) { return 15 * 17 * (n_fft / 256) + 
 constexpr int f64_fused_lds_bytes(int n_fft) { return 16 * f64_fused_lds_elems(n_fft); }
 // 8 wavefronts per CU (2 per SIMD) at every size: 8 / 4 / 2 workgroups
 constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
-hipError_t launch_spectra_f64_fused(const SpectraParamsF64&, int blocks, hipStream_t);
+hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
+hipError_t launch_spectra_f64_fused_2048(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
+hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 
 // Occupancy the fused kernel is built for (waves per SIMD = __launch_bounds__'
 // second argument), by instantiation, chosen so that NO instantiation spills
@@ -223,7 +240,7 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
 hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
                            float* d_out, hipStream_t);
 hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t);
-hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t);
+hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t, int device);
 hipError_t launch_welch_accumulate(double* d_acc, const double* d_part, int n, long frames_end, double* d_b, hipStream_t);
 hipError_t launch_welch_finish(double* d_acc, int n, long total, double* d_b, hipStream_t);
 hipError_t launch_payload_f64(const double* d_sums, int n, double gain, int count, uint8_t* d_out, hipStream_t);

@@ -54,7 +54,8 @@ struct Tables {
     float2* hann_cs = nullptr;      // fused: [T] (0.5 cos, 0.5 sin)(2 pi t / N)
     double2* tw64 = nullptr;        // f64 kernel: W_N^k, k < N
     double* hann64 = nullptr;
-    double2* tw1_64 = nullptr;      // f64 fused kernel (N = 1024): [T][16] W_N^(t*rev16(s)) / 128
+    double2* tw1_64 = nullptr;      // f64 fused kernel: [T][16] W_N^(t*rev16(s)) / 128
+    double2* tw1u_64 = nullptr;     //   ... unscaled (real f32 input)
     double2* tw2_64 = nullptr;      //   [16][R3/2] last-pass (cos, sin/cos) pairs
     double2* hann_cs64 = nullptr;   //   [T] (0.5 cos, 0.5 sin)(2 pi t / N)
 };
@@ -63,10 +64,23 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 
 }  // namespace
 
+// Kernel-selection switches (experiments, A/B runs, tests).  Read from the environment ONCE, when
+// the engine is created, and changed afterwards only through rtlws_engine_set_option: nothing on a
+// launch path calls getenv (tests/test_abi_cpu.py checks the library's imports per function).
+struct EngineOpts {
+    int v2 = -1;                 // RTLWS_V2: -1 = default rule (K = 1 rows), 0 / 1 = never / always
+    int blocks_per_cu = 0;       // RTLWS_BLOCKS_PER_CU: > 0 overrides the f32 fused kernels' grid
+    int f64_fused = 1;           // RTLWS_F64_FUSED=0: f64 batches stay on the row-per-workgroup kernel
+    int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
+    int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
+    int cic_round = 0;           // RTLWS_CIC_ROUND=1|2|4: LDS staging depth where R fits it
+};
+
 struct rtlws_engine {
     int device = 0;
     int cu_count = 256;
     hipStream_t stream = nullptr;
+    EngineOpts opt;
     std::mutex mu;
     std::map<int, Tables> tables;   // by n_fft (fused) or -n_fft (direct)
 };
@@ -115,6 +129,7 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.tw64);
     (void)hipFree(tb.hann64);
     (void)hipFree(tb.tw1_64);
+    (void)hipFree(tb.tw1u_64);
     (void)hipFree(tb.tw2_64);
     (void)hipFree(tb.hann_cs64);
     tb = Tables();
@@ -231,12 +246,13 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
                 *sn = sinl(a);
             }
         };
-        std::vector<double2> h1((size_t)T * 16), h2((size_t)NP * 16), hcs((size_t)T);
+        std::vector<double2> h1((size_t)T * 16), h1u((size_t)T * 16), h2((size_t)NP * 16), hcs((size_t)T);
         for (int t = 0; t < T; ++t) {
             for (int s = 0; s < 16; ++s) {
                 long double c, sn;
                 wn((long)t * rev16h(s), n_fft, &c, &sn);
                 h1[(size_t)t * 16 + s] = make_double2((double)(c * 0.0078125L), (double)(sn * 0.0078125L));
+                h1u[(size_t)t * 16 + s] = make_double2((double)c, (double)sn);
             }
             const long double a = two_pi * (long double)t / (long double)n_fft;
             hcs[t] = make_double2((double)(0.5L * cosl(a)), (double)(0.5L * sinl(a)));
@@ -251,7 +267,8 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
                     h2[(size_t)q2 * NP + k++] = make_double2((double)c, (double)(sn / c));
                 }
         }
-        if (!upload_table(h1, &tb.tw1_64) || !upload_table(h2, &tb.tw2_64) || !upload_table(hcs, &tb.hann_cs64)) {
+        if (!upload_table(h1, &tb.tw1_64) || !upload_table(h1u, &tb.tw1u_64) || !upload_table(h2, &tb.tw2_64) ||
+            !upload_table(hcs, &tb.hann_cs64)) {
             free_tables(tb);
             return -3;
         }
@@ -286,12 +303,12 @@ bool desc_ok(const rtlws_spectra_desc* d)
 // default only K = 1 rows take it: measured +4..8 % there (rect_4096pt 0.532 -> 0.577 of the HBM
 // roofline, Hann K = 1 0.471 -> 0.496) and -1..-4 % with K = 8 accumulators, where both kernels
 // deliver the same points per second (DESIGN.md, configs[2]).  RTLWS_V2=0|1 forces either
-// kernel for every K (A/B runs, tests/test_v2_gpu.py); read per call.
-bool use_v2(int n_fft, int in_kind, int k_avg)
+// kernel for every K at engine creation (rtlws_engine_set_option(e, "v2", ...) afterwards: A/B
+// runs, tests/test_v2_gpu.py).
+bool use_v2(const rtlws_engine* e, int n_fft, int in_kind, int k_avg)
 {
     if (!rtlws::fused_v2_kind(n_fft, in_kind)) return false;
-    const char* v = getenv("RTLWS_V2");
-    return (v && *v) ? (atoi(v) != 0) : (RTLWS_V2_DEFAULT != 0 && k_avg == 1);
+    return e->opt.v2 >= 0 ? (e->opt.v2 != 0) : (RTLWS_V2_DEFAULT != 0 && k_avg == 1);
 }
 
 int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0, bool win = false,
@@ -300,11 +317,8 @@ int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0
     // 4 x waves-per-SIMD wavefronts per CU, n_fft/1024 wavefronts per workgroup.
     // Persistent: each workgroup strides over the output rows.
     int per_cu = 4 * rtlws::fused_waves_per_simd(n_fft, in_kind, win, kone) / (n_fft / 1024);
-    if (use_v2(n_fft, in_kind, k_avg)) per_cu = rtlws::v2_blocks_per_cu(n_fft);
-    if (const char* ov = getenv("RTLWS_BLOCKS_PER_CU")) {   // experiments only
-        const int v = atoi(ov);
-        if (v > 0) per_cu = v;
-    }
+    if (use_v2(e, n_fft, in_kind, k_avg)) per_cu = rtlws::v2_blocks_per_cu(n_fft);
+    if (e->opt.blocks_per_cu > 0) per_cu = e->opt.blocks_per_cu;   // experiments only
     long blocks = (long)e->cu_count * per_cu;
     if (blocks > ngroups) blocks = ngroups;
     return (int)(blocks < 1 ? 1 : blocks);
@@ -335,6 +349,17 @@ rtlws_engine* rtlws_engine_create(int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         e->cu_count = prop.multiProcessorCount;
+    // the only place the library reads these variables
+    auto env_int = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return (v && *v) ? atoi(v) : dflt;
+    };
+    e->opt.v2 = env_int("RTLWS_V2", -1);
+    e->opt.blocks_per_cu = env_int("RTLWS_BLOCKS_PER_CU", 0);
+    e->opt.f64_fused = env_int("RTLWS_F64_FUSED", 1);
+    e->opt.f64_blocks_per_cu = env_int("RTLWS_F64_BLOCKS_PER_CU", 0);
+    e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
+    e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_err("hipStreamCreate", err);
@@ -355,6 +380,39 @@ void rtlws_engine_destroy(rtlws_engine* e)
 }
 
 int rtlws_engine_device(const rtlws_engine* e) { return e ? e->device : -1; }
+
+int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
+{
+    g_err.clear();
+    NEED_ENGINE(e, -1);
+    const std::string k = name ? name : "";
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (k == "v2") e->opt.v2 = value < 0 ? -1 : (value != 0);
+    else if (k == "blocks_per_cu") e->opt.blocks_per_cu = value > 0 ? value : 0;
+    else if (k == "f64_fused") e->opt.f64_fused = value != 0;
+    else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
+    else if (k == "cic_direct") e->opt.cic_direct = value != 0;
+    else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
+    else {
+        g_err = "rtlws_engine_set_option: unknown option '" + k + "'";
+        return -1;
+    }
+    return 0;
+}
+
+int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
+{
+    if (!e || !name) return -2;
+    const std::string k = name;
+    if (k == "v2") return e->opt.v2;
+    if (k == "blocks_per_cu") return e->opt.blocks_per_cu;
+    if (k == "f64_fused") return e->opt.f64_fused;
+    if (k == "f64_blocks_per_cu") return e->opt.f64_blocks_per_cu;
+    if (k == "cic_direct") return e->opt.cic_direct;
+    if (k == "cic_round") return e->opt.cic_round;
+    if (k == "cu_count") return e->cu_count;
+    return -2;
+}
 
 int rtlws_engine_prepare(rtlws_engine* e, int n_fft)
 {
@@ -538,18 +596,13 @@ float rtlws_event_elapsed_ms(void* start, void* stop)
 }
 
 // Input stage of the fused kernel for a CIC factor.  For A/B experiments
-// (tools/cic_fused_rates.py): RTLWS_CIC_DIRECT=1 keeps every R != 8 on the
-// per-lane direct loads, RTLWS_CIC_ROUND=1|2|4 forces the LDS staging depth
+// (tools/cic_fused_rates.py): option cic_direct keeps every R != 8 on the
+// per-lane direct loads, cic_round = 1|2|4 forces the LDS staging depth
 // where R fits it.
-static int cic_in_kind(int R)
+static int cic_in_kind(const rtlws_engine* e, int R)
 {
     if (R == 8) return rtlws::IN_CU8_CIC8;
-    static const int force = [] {
-        const char* v = getenv("RTLWS_CIC_DIRECT");
-        if (v && v[0] == '1') return -1;
-        v = getenv("RTLWS_CIC_ROUND");
-        return v ? atoi(v) : 0;
-    }();
+    const int force = e->opt.cic_direct ? -1 : e->opt.cic_round;
     if (force < 0) return rtlws::cicr_direct_kind(R);
     if (force == 1 || force == 2 || force == 4) {
         const int k = rtlws::cicr_lds_kind(R, force);
@@ -571,10 +624,10 @@ int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* d, long nframe
     const long ngroups = nframes / d->k_avg;
     if (is_fused_n(d->n_fft)) {
         int in_kind = d->input;
-        if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
+        if (d->cic_r > 1) in_kind = cic_in_kind(e, d->cic_r);
         if (blocks) *blocks = fused_blocks(e, d->n_fft, ngroups, in_kind, d->window == RTLWS_WIN_HANN,
                                            d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
-        const bool v2 = use_v2(d->n_fft, in_kind, d->k_avg);
+        const bool v2 = use_v2(e, d->n_fft, in_kind, d->k_avg);
         if (threads) *threads = v2 ? d->n_fft / 32 : d->n_fft / 16;
         if (lds_bytes) *lds_bytes = v2 ? rtlws::v2_lds_bytes(d->n_fft) : rtlws::fused_lds_bytes(d->n_fft, in_kind, d->window == RTLWS_WIN_HANN);
     } else {
@@ -624,7 +677,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     p.lin_gain = (float)(std::pow(10.0, (double)(d->gain_db / 10)) / (double)d->k_avg);
 
     int in_kind = d->input;
-    if (d->cic_r > 1) in_kind = cic_in_kind(d->cic_r);
+    if (d->cic_r > 1) in_kind = cic_in_kind(e, d->cic_r);
 
     HIP_TRY(hipSetDevice(e->device), -3);
     hipStream_t st = pick_stream(e, stream);
@@ -632,7 +685,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
     if (fused) {
         const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
                                         d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
-        if (use_v2(d->n_fft, in_kind, d->k_avg)) err = rtlws::launch_spectra_fused_v2(p, blocks, st);
+        if (use_v2(e, d->n_fft, in_kind, d->k_avg)) err = rtlws::launch_spectra_fused_v2(p, blocks, st);
         else switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
         case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;
@@ -677,8 +730,9 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
         return -1;
     }
     if (nframes == 0) return 0;
-    if ((reinterpret_cast<uintptr_t>(d_in) & 7u) || (reinterpret_cast<uintptr_t>(d_out) & 7u)) {
-        g_err = "rtlws_spectra_batch_f64: d_in and d_out must be 8-byte aligned";
+    const unsigned out_align = ((d->flags & RTLWS_FLAG_ROWS_F32) || d->output == RTLWS_OUT_PAYLOAD_U8) ? 3u : 7u;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 7u) || (reinterpret_cast<uintptr_t>(d_out) & out_align)) {
+        g_err = "rtlws_spectra_batch_f64: d_in must be 8-byte aligned, d_out 8-byte (4-byte for f32 rows and payload bytes)";
         return -1;
     }
     Tables tb;
@@ -703,27 +757,35 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     p.lin_gain = std::pow(10.0, (double)(d->gain_db / 10));
     p.in_scale = (d->input != RTLWS_IN_RF32) ? 0.0078125 : 1.0;
 
-    p.tw1f = tb.tw1_64;
+    p.tw1f = (d->input == RTLWS_IN_RF32) ? tb.tw1u_64 : tb.tw1_64;
     p.tw2f = tb.tw2_64;
     p.hann_csf = tb.hann_cs64;
+    p.rows_f32 = (d->flags & RTLWS_FLAG_ROWS_F32) && d->output != RTLWS_OUT_PAYLOAD_U8;
+
+    int in_kind = d->input;
+    if (d->cic_r > 1) in_kind = cic_in_kind(e, d->cic_r);
+    // the fused kernel's vector accesses: 16-byte rows at N = 1024 (either row precision), 16-byte
+    // input pieces on the CIC-fused kinds; anything less aligned takes the general kernel
+    const bool aligned = !(reinterpret_cast<uintptr_t>(d_out) & 15u) &&
+                         (in_kind < rtlws::IN_CU8_CIC8 || !(reinterpret_cast<uintptr_t>(d_in) & 15u));
 
     HIP_TRY(hipSetDevice(e->device), -3);
+    hipStream_t st = pick_stream(e, stream);
     hipError_t err;
-    // 1024-point cmplx_u8 frames: the fused throughput kernel (spectrum_f64_fused.hip);
-    // RTLWS_F64_FUSED=0 keeps them on the row-per-workgroup kernel (A/B runs, tests)
-    const char* ff = getenv("RTLWS_F64_FUSED");
-    if (rtlws::f64_fused_kind(d->n_fft, d->input, d->cic_r) && !(ff && ff[0] == '0') &&
-        !(reinterpret_cast<uintptr_t>(d_out) & 15u)) {
+    // the fused throughput kernel (spectrum_f64_fused.hip) where it exists; option f64_fused = 0
+    // keeps everything on the row-per-workgroup kernel (A/B runs, tests)
+    if (rtlws::f64_fused_kind(d->n_fft, in_kind) && e->opt.f64_fused && aligned) {
         int per_cu = rtlws::f64_fused_blocks_per_cu(d->n_fft);
-        if (const char* ov = getenv("RTLWS_F64_BLOCKS_PER_CU")) {   // experiments only
-            const int v = atoi(ov);
-            if (v > 0 && v <= per_cu + 1) per_cu = v;
-        }
+        if (e->opt.f64_blocks_per_cu > 0 && e->opt.f64_blocks_per_cu <= per_cu + 1) per_cu = e->opt.f64_blocks_per_cu;
         long blocks = (long)e->cu_count * per_cu;
         if (blocks > p.ngroups) blocks = p.ngroups;
-        err = rtlws::launch_spectra_f64_fused(p, (int)blocks, pick_stream(e, stream));
+        switch (d->n_fft) {
+        case 1024: err = rtlws::launch_spectra_f64_fused_1024(p, in_kind, (int)blocks, st, e->device); break;
+        case 2048: err = rtlws::launch_spectra_f64_fused_2048(p, in_kind, (int)blocks, st, e->device); break;
+        default: err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, (int)blocks, st, e->device); break;
+        }
     } else {
-        err = rtlws::launch_spectra_f64(p, d->input, pick_stream(e, stream));
+        err = rtlws::launch_spectra_f64(p, d->input, st, e->device);
     }
     if (err != hipSuccess) {
         set_err("f64 spectra kernel launch", err);

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "rtlws_internal.h"
 
 namespace rtlws {
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(256) void spectra_f64(const SpectraParamsF64 p)
                 const double d = 10.0 * log10(fabs(p.lin_gain * a / (double)p.count));
                 const unsigned m = (d >= 0.0) ? (d <= 255.0 ? (unsigned)(int)d : 255u) : 0u;
                 reinterpret_cast<uint8_t*>(p.out)[g * N + i] = (uint8_t)m;
-            } else if (p.out_mode == OUT_DB) {
-                reinterpret_cast<double*>(p.out)[g * N + i] = 10.0 * log10(a / (double)p.count);
             } else {
-                reinterpret_cast<double*>(p.out)[g * N + i] = a;
+                const double o = (p.out_mode == OUT_DB) ? 10.0 * log10(a / (double)p.count) : a;
+                if (p.rows_f32) reinterpret_cast<float*>(p.out)[g * N + i] = (float)o;   // RTLWS_FLAG_ROWS_F32
+                else reinterpret_cast<double*>(p.out)[g * N + i] = o;
             }
         }
     }
@@ -206,23 +208,28 @@ hipError_t launch_welch_finish(double* d_acc, int n, long total, double* d_b, hi
 }
 
 template <int IN>
-static hipError_t launch_f64_in(const SpectraParamsF64& p, hipStream_t st)
+static hipError_t launch_f64_in(const SpectraParamsF64& p, hipStream_t st, int device)
 {
     const size_t lds_bytes = sizeof(double2) * (size_t)p.n_fft;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64<IN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
+    if (lds_bytes > 64 * 1024) {       // 4096 < N <= 8192: raised once per device to the most any N needs
+        static std::atomic<unsigned long long> ready{0};
+        const unsigned long long bit = 1ull << (device & 63);
+        if (!(ready.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64<IN>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double2) * 8192));
+            if (e != hipSuccess) return e;
+            ready.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL((spectra_f64<IN>), dim3((unsigned)p.ngroups), dim3(256), lds_bytes, st, p);
     return hipGetLastError();
 }
 
-hipError_t launch_spectra_f64(const SpectraParamsF64& p, int in_kind, hipStream_t st)
+hipError_t launch_spectra_f64(const SpectraParamsF64& p, int in_kind, hipStream_t st, int device)
 {
-    if (in_kind == IN_CS32) return launch_f64_in<IN_CS32>(p, st);
-    if (in_kind == IN_RF32) return launch_f64_in<IN_RF32>(p, st);
-    return launch_f64_in<IN_CU8>(p, st);
+    if (in_kind == IN_CS32) return launch_f64_in<IN_CS32>(p, st, device);
+    if (in_kind == IN_RF32) return launch_f64_in<IN_RF32>(p, st, device);
+    return launch_f64_in<IN_CU8>(p, st, device);
 }
 
 }  // namespace rtlws

@@ -11,8 +11,16 @@
 // barrier, two at 2048, four at 4096 -- sixteen complex points per lane, two LDS
 // transpositions) with every value a double: strict-metric error (floor 1e-9 of the row
 // maximum) ~1e-12, i.e. rtlws_spectra_batch_f64 at batch rates instead of one
-// workgroup-per-row radix-2 (spectrum_f64.hip, which keeps every other N, the cmplx_s32 /
-// real-f32 inputs and the CIC-fused form).
+// workgroup-per-row radix-2 (spectrum_f64.hip, which keeps every other N and the generic CIC
+// factors).  Round 4: compiled once per size (-DRTLWS_N=1024|2048|4096) for
+//   * every input kind of spectrum.h -- cmplx_u8, cmplx_s32 (src/spectrum.c:72-76), real f32
+//     (:90-94) -- and the CIC-fused input stage for R = 8 and the reference's own factors 10 and 12
+//     (src/resample.c:21-40 feeding src/spectrum.c:65-81: BASELINE configs[3] in the reference's
+//     precision); the input stages are frame_input.h, the integer block sums are exact in double;
+//   * ROWF32: f64 arithmetic, rows rounded ONCE to f32 on the store (RTLWS_FLAG_ROWS_F32) -- the
+//     contract's own byte count (2N + 4N/K per frame) with the strict-metric error
+//     of one f32 rounding (<= 6e-8) instead of an f32 transform's.  A lane's four bins are then 16
+//     bytes: one store instruction writes 1 KiB of consecutive bytes without any lane exchange.
 //
 // Cost model (MI355X): v_fma_f64 / v_add_f64 / v_mul_f64 issue at 4 cycles per wave64
 // instruction -- half the f32 rate, and the rate ONE wavefront can issue at by itself, so 2
@@ -32,18 +40,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "rtlws_internal.h"
+#include "cic_lds.h"
+#include "frame_input.h"
 #include "fft_regs_f64.h"
+
+#ifndef RTLWS_N
+#error "compile with -DRTLWS_N=1024|2048|4096"
+#endif
 
 namespace rtlws {
 
 using namespace f64;      // f2 = double2, real = double, fft16_fma, fft_last, hann_w ... in double
 
-template <int N, bool WIN, int OUT, bool KONE>
+template <int N, int IN, bool WIN, int OUT, bool KONE, bool ROWF32>
 __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraParamsF64 p)
 {
     constexpr int T = N / 16, R3 = N / 256, J = 16 / R3;
     constexpr int F64F_ROW = 17 * R3;
+    static_assert(!(ROWF32 && OUT == OUT_PAYLOAD), "payload rows are bytes in either form");
+    static_assert(IN < IN_CU8_CICR_LDS4 || (N / 1024) * cic_stage_wave_bytes(IN) <= f64_fused_lds_bytes(N) - 16,
+                  "the CIC staging slices live in the transposition buffer");
     extern __shared__ __attribute__((aligned(16))) double2 ldsd[];
 
     const int t = threadIdx.x;
@@ -62,12 +81,14 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
         for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + T * r + t);
 #endif
     };
-    if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
+    if constexpr (IN == IN_CU8) {
+        if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
+    }
 
     // the last pass's (cos, tan) pairs stay in registers, except in the one instantiation whose
     // budget they break (4096-point, window, K-frame accumulators: 32 VGPRs of pairs): there
     // they are re-read from the (L2-resident, 2 KiB) table every frame, under the LDS reads
-    constexpr bool TW3_REGS = !(N == 4096 && WIN && !KONE);
+    constexpr bool TW3_REGS = f64_fused_tw3_regs(N, IN, WIN, KONE);
     f2 tw1[16], tw3[R3 / 2];
 #pragma unroll
     for (int s = 0; s < 16; ++s) tw1[s] = p.tw1f[t * 16 + s];
@@ -105,24 +126,35 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             const long frame = g * K + kf;
             f2 v[16];
             if constexpr (WIN && !WINREGS) asm volatile("" : "+v"(wcs.x), "+v"(wcs.y));   // not hoisted
+            if constexpr (IN == IN_CU8) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // (double)u8 is exact; the 128 offset is kept on the rectangular path (it only
-                // reaches bin 0, which is never output: src/spectrum.c:31) and folded into one
-                // FMA on the windowed one ((x - 128) * w, -128 * w exact)
-                const double re = (double)(raw[r] & 0xffu), im = (double)((raw[r] >> 8) & 0xffu);
-                if constexpr (WIN) {
-                    const double w = WINREGS ? win[r] : hann_w(r, wcs), c = -128.0 * w;
-                    v[r] = mk(fma(re, w, c), fma(im, w, c));
-                } else {
-                    v[r] = mk(re, im);
+                for (int r = 0; r < 16; ++r) {
+                    // (double)u8 is exact; the 128 offset is kept on the rectangular path (it only
+                    // reaches bin 0, which is never output: src/spectrum.c:31) and folded into one
+                    // FMA on the windowed one ((x - 128) * w, -128 * w exact)
+                    const double re = (double)(raw[r] & 0xffu), im = (double)((raw[r] >> 8) & 0xffu);
+                    if constexpr (WIN) {
+                        const double w = WINREGS ? win[r] : hann_w(r, wcs), c = -128.0 * w;
+                        v[r] = mk(fma(re, w, c), fma(im, w, c));
+                    } else {
+                        v[r] = mk(re, im);
+                    }
                 }
-            }
-            {
                 long nf = frame + 1;
                 if (kf + 1 == K) nf = (g + gridDim.x) * K;
                 if (nf >= ngroups * K) nf = frame;        // in bounds, result unused
                 load_raw(nf);
+            } else {
+                // cmplx_s32 / real f32 / CIC-fused block sums (frame_input.h): integers and floats,
+                // exact in double; the 1/128 scale rides on the pass-1 twiddles as for cmplx_u8
+                load_frame_points<N, IN>(p, frame, t, v, ldsd);
+                if constexpr (WIN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const double w = WINREGS ? win[r] : hann_w(r, wcs);
+                        v[r] = mk(v[r].x * w, v[r].y * w);
+                    }
+                }
             }
 
             // ---- pass 1: radix-16 over the slow digit, twiddle W_N^(m1*q1) (carries the 1/128)
@@ -218,6 +250,33 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
                 else if constexpr (J == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
                 else *dst = (uint8_t)packed;
             }
+        } else if constexpr (ROWF32) {
+            // f32 rows: the lane's J consecutive bins are 4*J bytes -- 16 / 8 / 4 per lane, every
+            // store instruction consecutive bytes (1 KiB at N = 1024) with no lane exchange; one
+            // rounding per value, after the dB conversion where there is one
+#pragma unroll
+            for (int s = 0; s < R3; ++s) {
+                const int i0 = 256 * (rev_last<R3>(s) ^ (R3 / 2)) + J * t;
+                float o[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    double a = acc[j * R3 + s];
+                    if constexpr (OUT == OUT_DB) a = 10.0 * log10(a / (double)p.count);
+                    o[j] = (float)a;
+                }
+                float* dst = reinterpret_cast<float*>(p.out) + g * N + i0;
+                if constexpr (J == 4) {
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const nt_f4 ov = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(dst));
+                } else if constexpr (J == 2) {
+                    typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                    const nt_f2 ov = {o[0], o[1]};
+                    __builtin_nontemporal_store(ov, reinterpret_cast<nt_f2*>(dst));
+                } else {
+                    __builtin_nontemporal_store(o[0], dst);
+                }
+            }
         } else if constexpr (J == 4) {
             // N = 1024: a lane owns four consecutive bins = 32 bytes = 16-byte pieces A_t | B_t.
             // v_permlane32_swap exchanges the upper 32 lanes of A with the lower 32 lanes of B:
@@ -282,47 +341,74 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
     }
 }
 
-template <int N, bool WIN, int OUT>
-static hipError_t launch_f64f_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
+// ---- launch table (this file is compiled once per RTLWS_N) -----------------
+
+// N = 4096 needs 69.6 KiB of LDS per workgroup: the attribute is set once per instantiation and
+// device (a bit per device; the launch path itself makes no other HIP call than the launch)
+template <int N, int IN, bool WIN, int OUT, bool KONE, bool ROWF32>
+static hipError_t launch_f64f_one(const SpectraParamsF64& p, int blocks, hipStream_t st, int device)
 {
-    const size_t lds_bytes = f64_fused_lds_bytes(N);
-    if (lds_bytes > 64 * 1024) {       // N = 4096: 69.6 KiB per workgroup
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_fused<N, WIN, OUT, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_fused<N, WIN, OUT, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
+    constexpr size_t lds_bytes = f64_fused_lds_bytes(N);
+    if constexpr (lds_bytes > 64 * 1024) {
+        static std::atomic<unsigned long long> ready{0};
+        const unsigned long long bit = 1ull << (device & 63);
+        if (!(ready.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&spectra_f64_fused<N, IN, WIN, OUT, KONE, ROWF32>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            ready.fetch_or(bit, std::memory_order_release);
+        }
     }
-    if (p.k_avg == 1)
-        hipLaunchKernelGGL((spectra_f64_fused<N, WIN, OUT, true>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL((spectra_f64_fused<N, WIN, OUT, false>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
+    hipLaunchKernelGGL((spectra_f64_fused<N, IN, WIN, OUT, KONE, ROWF32>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
     return hipGetLastError();
 }
 
-template <int N, bool WIN>
-static hipError_t launch_f64f_o(const SpectraParamsF64& p, int blocks, hipStream_t st)
+template <int N, int IN, bool WIN, int OUT, bool ROWF32>
+static hipError_t launch_f64f_k(const SpectraParamsF64& p, int blocks, hipStream_t st, int device)
+{
+    // K == 1 gets its own instantiation (no accumulators) on the kinds that have one in the f32
+    // kernel too; cmplx_s32 / real f32 share the general-K code
+    if constexpr (fused_kone_kind(IN)) {
+        if (p.k_avg == 1) return launch_f64f_one<N, IN, WIN, OUT, true, ROWF32>(p, blocks, st, device);
+    }
+    return launch_f64f_one<N, IN, WIN, OUT, false, ROWF32>(p, blocks, st, device);
+}
+
+template <int N, int IN, bool WIN>
+static hipError_t launch_f64f_o(const SpectraParamsF64& p, int blocks, hipStream_t st, int device)
 {
     switch (p.out_mode) {
-    case OUT_SUM: return launch_f64f_k<N, WIN, OUT_SUM>(p, blocks, st);
-    case OUT_DB: return launch_f64f_k<N, WIN, OUT_DB>(p, blocks, st);
-    default: return launch_f64f_k<N, WIN, OUT_PAYLOAD>(p, blocks, st);
+    case OUT_SUM:
+        return p.rows_f32 ? launch_f64f_k<N, IN, WIN, OUT_SUM, true>(p, blocks, st, device)
+                          : launch_f64f_k<N, IN, WIN, OUT_SUM, false>(p, blocks, st, device);
+    case OUT_DB:
+        return p.rows_f32 ? launch_f64f_k<N, IN, WIN, OUT_DB, true>(p, blocks, st, device)
+                          : launch_f64f_k<N, IN, WIN, OUT_DB, false>(p, blocks, st, device);
+    default: return launch_f64f_k<N, IN, WIN, OUT_PAYLOAD, false>(p, blocks, st, device);
     }
 }
 
-template <int N>
-static hipError_t launch_f64f_w(const SpectraParamsF64& p, int blocks, hipStream_t st)
+template <int N, int IN>
+static hipError_t launch_f64f_w(const SpectraParamsF64& p, int blocks, hipStream_t st, int device)
 {
-    return p.window ? launch_f64f_o<N, true>(p, blocks, st) : launch_f64f_o<N, false>(p, blocks, st);
+    return p.window ? launch_f64f_o<N, IN, true>(p, blocks, st, device) : launch_f64f_o<N, IN, false>(p, blocks, st, device);
 }
 
-hipError_t launch_spectra_f64_fused(const SpectraParamsF64& p, int blocks, hipStream_t st)
+#define RTLWS_CAT2(a, b) a##b
+#define RTLWS_CAT(a, b) RTLWS_CAT2(a, b)
+
+hipError_t RTLWS_CAT(launch_spectra_f64_fused_, RTLWS_N)(const SpectraParamsF64& p, int in_kind, int blocks,
+                                                         hipStream_t st, int device)
 {
-    switch (p.n_fft) {
-    case 1024: return launch_f64f_w<1024>(p, blocks, st);
-    case 2048: return launch_f64f_w<2048>(p, blocks, st);
-    case 4096: return launch_f64f_w<4096>(p, blocks, st);
+    constexpr int N = RTLWS_N;
+    switch (in_kind) {
+    case IN_CU8: return launch_f64f_w<N, IN_CU8>(p, blocks, st, device);
+    case IN_CS32: return launch_f64f_w<N, IN_CS32>(p, blocks, st, device);
+    case IN_RF32: return launch_f64f_w<N, IN_RF32>(p, blocks, st, device);
+    case IN_CU8_CIC8: return launch_f64f_w<N, IN_CU8_CIC8>(p, blocks, st, device);
+    case IN_CU8_CIC10: return launch_f64f_w<N, IN_CU8_CIC10>(p, blocks, st, device);
+    case IN_CU8_CIC12: return launch_f64f_w<N, IN_CU8_CIC12>(p, blocks, st, device);
     default: return hipErrorInvalidValue;
     }
 }

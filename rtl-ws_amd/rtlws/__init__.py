@@ -29,6 +29,7 @@ SYNTH_LIB = os.path.join(LIB_DIR, "librtlws_synth.so")   # synthetic rtl_sensor.
 IN_CU8, IN_CS32, IN_RF32 = 0, 1, 2
 WIN_RECT, WIN_HANN = 0, 1
 OUT_POWER_SUM, OUT_MEAN_DB, OUT_PAYLOAD_U8 = 0, 1, 2
+FLAG_ROWS_F32 = 1          # rtlws_spectra_batch_f64: f64 arithmetic, f32 rows
 
 _INPUTS = {"cu8": IN_CU8, "cs32": IN_CS32, "rf32": IN_RF32}
 _WINDOWS = {"rect": WIN_RECT, "hann": WIN_HANN, None: WIN_RECT}
@@ -44,7 +45,7 @@ def build(jobs=8):
 
 class SpectraDesc(C.Structure):
     _fields_ = [("n_fft", C.c_int), ("k_avg", C.c_int), ("input", C.c_int), ("window", C.c_int),
-                ("output", C.c_int), ("cic_r", C.c_int), ("gain_db", C.c_int), ("reserved", C.c_int)]
+                ("output", C.c_int), ("cic_r", C.c_int), ("gain_db", C.c_int), ("flags", C.c_int)]
 
 
 class CmplxS32(C.Structure):
@@ -58,7 +59,7 @@ class CicDelayLine(C.Structure):
 # every symbol include/*.h declares, by library (tests check the exports)
 HIP_SYMBOLS = [
     "rtlws_device_count", "rtlws_engine_create", "rtlws_engine_destroy", "rtlws_engine_device",
-    "rtlws_engine_prepare",
+    "rtlws_engine_prepare", "rtlws_engine_set_option", "rtlws_engine_get_option",
     "rtlws_last_error", "rtlws_dev_alloc", "rtlws_dev_free", "rtlws_pinned_alloc",
     "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
@@ -120,6 +121,8 @@ def hip_lib():
         L.rtlws_engine_destroy.argtypes = [vp]
         L.rtlws_engine_device.argtypes = [vp]
         L.rtlws_engine_prepare.argtypes = [vp, i]
+        L.rtlws_engine_set_option.argtypes = [vp, C.c_char_p, i]
+        L.rtlws_engine_get_option.argtypes = [vp, C.c_char_p]
         L.rtlws_last_error.restype = C.c_char_p
         L.rtlws_dev_alloc.argtypes = [vp, sz]
         L.rtlws_dev_alloc.restype = vp
@@ -213,9 +216,9 @@ def torch_stream_handle(stream=None):
     return h if h else STREAM_DEFAULT
 
 
-def make_desc(n_fft, k_avg=1, input="cu8", window="rect", output="power_sum", cic_r=0, gain_db=0):
+def make_desc(n_fft, k_avg=1, input="cu8", window="rect", output="power_sum", cic_r=0, gain_db=0, flags=0):
     return SpectraDesc(int(n_fft), int(k_avg), _INPUTS.get(input, input), _WINDOWS.get(window, window),
-                       _OUTPUTS.get(output, output), int(cic_r), int(gain_db), 0)
+                       _OUTPUTS.get(output, output), int(cic_r), int(gain_db), int(flags))
 
 
 class DevBuf:
@@ -278,6 +281,26 @@ class Engine:
     def sync(self, stream=None):
         self._chk(hip_lib().rtlws_stream_sync(self.h, stream), "sync")
 
+    def set_option(self, name, value):
+        """Kernel-selection switch of this engine (include/rtlws_hip.h: rtlws_engine_set_option)."""
+        self._chk(hip_lib().rtlws_engine_set_option(self.h, name.encode(), int(value)), "set_option(%s)" % name)
+
+    def get_option(self, name):
+        return hip_lib().rtlws_engine_get_option(self.h, name.encode())
+
+    def option(self, name, value):
+        """Context manager: the option set to `value` inside the block, restored afterwards."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = eng.get_option(name)
+                eng.set_option(name, value)
+
+            def __exit__(self_, *exc):
+                eng.set_option(name, self_.old)
+        return _Scope()
+
     def _chk(self, rc, what):
         if rc != 0:
             raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, last_error()))
@@ -320,15 +343,17 @@ class Engine:
 
     # -- convenience: host arrays in, host arrays out ------------------------
     def spectra(self, data, n_fft, k_avg=1, input="cu8", window="rect", output="power_sum",
-                cic_r=0, gain_db=0, f64=False):
-        """f64=True: rtlws_spectra_batch_f64 (the reference-precision kernel, f64 rows)."""
-        desc = make_desc(n_fft, k_avg, input, window, output, cic_r, gain_db)
+                cic_r=0, gain_db=0, f64=False, rows_f32=False):
+        """f64=True: rtlws_spectra_batch_f64 (the reference-precision kernels, f64 rows;
+        rows_f32=True: the same arithmetic with rows rounded once to f32, RTLWS_FLAG_ROWS_F32)."""
+        desc = make_desc(n_fft, k_avg, input, window, output, cic_r, gain_db,
+                         FLAG_ROWS_F32 if (f64 and rows_f32) else 0)
         data = np.ascontiguousarray(data)
         per_sample = {"cu8": 2, "cs32": 8, "rf32": 4}[input] * max(int(cic_r), 1)
         nframes = data.nbytes // (per_sample * n_fft)
         assert nframes * per_sample * n_fft == data.nbytes
         rows = nframes // k_avg
-        out_dtype = np.uint8 if output == "payload_u8" else (np.float64 if f64 else np.float32)
+        out_dtype = np.uint8 if output == "payload_u8" else (np.float64 if (f64 and not rows_f32) else np.float32)
         d_in = self.upload(data)
         d_out = self.alloc(rows * n_fft * np.dtype(out_dtype).itemsize)
         (self.spectra_batch_f64 if f64 else self.spectra_batch)(desc, d_in, nframes, d_out)

@@ -26,7 +26,16 @@ def test_workload_table_is_consistent():
     assert bench.algorithmic_bytes_per_frame(1024, 6, 0, "payload_u8") == 2048 + 1024 // 6
     assert bench.algorithmic_bytes_per_frame(2048, 1, 8, "cs32") == 2 * 2048 * 8 + 8 * 2048
     assert bench.algorithmic_bytes_per_frame(1024, 1, 0, "power_sum", f64=True) == 10240   # 2N + 8N/K
-    assert set(bench.F64_WORKLOADS) <= set(bench.WORKLOADS)
+    assert set(bench.F64_WORKLOADS) <= set(bench.WORKLOADS) and set(bench.F64C_F32O_WORKLOADS) <= set(bench.WORKLOADS)
+    assert not set(bench.F64_WORKLOADS) & set(bench.F64C_F32O_WORKLOADS)
+    assert bench.algorithmic_bytes_per_frame(2048, 1, 8, "power_sum", f64=True) == 49152           # configs[3], f64 rows
+    assert bench.precision_of("batched_1024pt_64k_frames_f64c_f32o") == "f64c_f32o"
+    assert bench.precision_of("cic8_2048pt_f64") == "f64" and bench.precision_of("cic8_2048pt") == "f32"
+    assert bench.parity_bounds_for("cic8_2048pt") is None
+    assert bench.parity_bounds_for("cic8_2048pt_f64")["max_rel_err_floor1e-9"] == 1e-10
+    assert bench.parity_bounds_for("cic8_2048pt_f64c_f32o")["max_rel_err_floor1e-9"] <= 6e-8
+    # every BASELINE.json configuration on the default line has the CPU path timed beside it
+    assert set(bench.EXTRA_CPU_BASELINE) == {"hann_4096pt_k8_db", "cic8_2048pt"} <= set(bench.EXTRA_WORKLOADS)
 
 
 @pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt",
@@ -78,6 +87,31 @@ def test_cpu_baseline_block_bookkeeping(oracle):
     assert out["unit"] == "samples/s" and out["cores"] == 1 and out["value"] > 0
 
 
+def test_cpu_baseline_block_windowed_and_cic_cases(oracle, monkeypatch):
+    """configs[2] (Hann, K = 8, mean dB) and configs[3] (CIC 8:1 + 2048-point): the window and the
+    decimator reach the oracle call that is timed, K-groups stay whole, the sample text says so."""
+    import torch
+    import bench
+    from rtlws import synth
+    seen = []
+    real_u8, real_cic = oracle.batch_spectra_u8, oracle.batch_spectra_cic_u8
+    monkeypatch.setattr(oracle, "batch_spectra_u8", lambda h, n, **kw: (seen.append(("u8", n, kw)), real_u8(h, n, **kw))[1])
+    monkeypatch.setattr(oracle, "batch_spectra_cic_u8", lambda h, n, r, **kw: (seen.append(("cic", n, r, kw)), real_cic(h, n, r, **kw))[1])
+    wl = bench.WORKLOADS["hann_4096pt_k8_db"]
+    dev_in = torch.from_numpy(synth.tone_noise_iq(64, 4096, seed=5))
+    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 64, budget_scale=0.01)
+    assert out["value"] > 0 and out["one_thread"]["value"] > 0 and "Hann, mean dB" in out["sample"] and "K = 8" in out["sample"]
+    assert seen and all(k[0] == "u8" and k[1] == 4096 and k[2]["K"] == 8 for k in seen)
+    assert all(np.allclose(k[2]["window"], synth.hann(4096)) for k in seen)
+    assert all(k[2]["out"].shape[0] * 8 <= 64 for k in seen)
+    seen.clear()
+    wl = bench.WORKLOADS["cic8_2048pt"]
+    dev_in = torch.from_numpy(synth.uniform_iq(16, 2048 * 8, seed=6))
+    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 16, budget_scale=0.01)
+    assert out["value"] > 0 and "CIC 8:1 first" in out["sample"]
+    assert seen and all(k[0] == "cic" and k[1] == 2048 and k[2] == 8 and k[3]["window"] is None for k in seen)
+
+
 def test_parity_block_names_constant_input_rows_instead_of_dividing_by_zero(oracle):
     """the driver's cic12 block was 0/0 = NaN with exit code 0.  A constant
     input frame (all-zero oracle row) must be reported as such and fail the run."""
@@ -118,6 +152,9 @@ def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
     out = bench.valu_issue_frac("w", 80e-6, 256)
     # 8e7 issue cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
     assert abs(out["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.0e9)) < 1e-12
+    assert "ANOTHER launch series" in out["valu_issue_source"]
+    own = bench.valu_issue_frac("w", 80e-6, 256, sclk_ghz=2.2)      # the run's own clock: what a line may carry
+    assert abs(own["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.2e9)) < 1e-12 and "own shader clock" in own["valu_issue_source"]
     assert bench.valu_issue_frac("other", 80e-6, 256) is None
 
 

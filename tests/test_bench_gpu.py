@@ -35,22 +35,30 @@ def _small_frames(bench, name):
 @pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt",
                                   "cic10_2048pt", "k6_1024pt_payload", "cic8_block_sums",
                                   "batched_1024pt_64k_frames_f64", "hann_4096pt_k8_db_f64", "rect_2048pt_f64",
-                                  "rect_4096pt", "hann_4096pt_k1_db"])
+                                  "rect_4096pt", "hann_4096pt_k1_db",
+                                  "batched_1024pt_64k_frames_f64c_f32o", "hann_4096pt_k8_db_f64c_f32o",
+                                  "cic8_2048pt_f64", "cic12_2048pt_f64", "cic8_2048pt_f64c_f32o"])
 def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeypatch):
     import bench
     monkeypatch.setattr(bench, "SETTLE_LAUNCHES", 40)        # the ordering matters here, not the governor
-    f64 = name in bench.F64_WORKLOADS
+    prec = bench.precision_of(name)
     runs = [bench.run_workload(ctx, name, steps=8, warmup=0, sets=4, frames_override=_small_frames(bench, name))
             for _ in range(2)]
     for r in runs:
         par = r["parity"]
         assert "failed" not in par and not par.get("non_finite"), par
-        assert bench.parity_failures(par, bench.PARITY_BOUNDS_F64 if f64 else None) == []
+        assert bench.parity_failures(par, bench.parity_bounds_for(name)) == []
         json.loads(json.dumps(bench.strict_json(r), allow_nan=False))          # strict JSON
         roof = r["roofline"]
         assert roof["frac_clock"] == "hip_events_on_launch_stream" and roof["frac_wall"] > 0
         assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
-        assert r["dtype"] == ("int32" if name == "cic8_block_sums" else ("f64" if f64 else "f32"))
+        assert r["dtype"] == ("int32" if name == "cic8_block_sums" else
+                              {"f32": "f32", "f64": "f64", "f64c_f32o": "f64 arithmetic, f32 rows"}[prec])
+        assert "valu_issue_frac" not in roof                  # no shader clock of THIS run: no such field
+        n_fft, k_avg, _, output, cic_r, _ = bench.WORKLOADS[name]
+        if output in ("power_sum", "mean_db"):               # rows priced at what was stored
+            per_frame = 2 * n_fft * max(cic_r, 1) + (8 if prec == "f64" else 4) * n_fft // k_avg
+            assert roof["algorithmic_bytes_per_launch"] == per_frame * r["config"]["frames_per_step"]
     assert runs[0]["parity"] == runs[1]["parity"]             # same seed, same kernel: identical statistics
 
 

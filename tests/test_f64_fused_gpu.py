@@ -2,8 +2,6 @@
 rates -- against the f64 oracle under the STRICT metric (floor 1e-9 of the row maximum,
 bound 1e-10: north_star's 1e-4 with six orders to spare), against the row-per-workgroup
 f64 kernel it replaces for that shape, and byte for byte on the payload."""
-import os
-
 import numpy as np
 import pytest
 
@@ -14,11 +12,8 @@ STRICT_F64 = 1e-10
 
 
 def _old_kernel(engine, iq, n_fft=1024, **kw):
-    os.environ["RTLWS_F64_FUSED"] = "0"
-    try:
+    with engine.option("f64_fused", 0):       # the row-per-workgroup kernel (spectrum_f64.hip)
         return engine.spectra(iq, n_fft, f64=True, **kw)
-    finally:
-        os.environ.pop("RTLWS_F64_FUSED", None)
 
 
 @pytest.mark.parametrize("window", ["rect", "hann"])

@@ -3,8 +3,6 @@ the four-wavefront kernel it replaces: the arithmetic is the same instruction fo
 instruction, so every output must be BIT-identical, for every window / K / output mode --
 and both are held to the oracle by the rest of the suite (which now runs the v2 kernel
 wherever it applies)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -12,17 +10,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(engine, iq, n_fft=4096, **kw):
-    old = os.environ.get("RTLWS_V2")
-    try:
-        os.environ["RTLWS_V2"] = "1"
+    """The kernel choice is an engine option (rtlws_engine_set_option), frozen between calls:
+    the environment is only read when an engine is created."""
+    dflt = engine.get_option("v2")
+    with engine.option("v2", 1):
         a = engine.spectra(iq, n_fft, **kw)
-        os.environ["RTLWS_V2"] = "0"
+    with engine.option("v2", 0):
         b = engine.spectra(iq, n_fft, **kw)
-    finally:
-        if old is None:
-            os.environ.pop("RTLWS_V2", None)
-        else:
-            os.environ["RTLWS_V2"] = old
+    assert engine.get_option("v2") == dflt       # the engine's own rule is back
     return a, b
 
 
@@ -35,11 +30,8 @@ def test_v2_bit_identical_to_the_four_wavefront_kernel(engine, built, window, k_
     iq[5] = 128                                   # a constant frame (all bins zero)
     iq[7] = synth.uniform_iq(1, 4096, seed=3)[0]
     desc = built.make_desc(4096, k_avg, "cu8", window, output)
-    os.environ["RTLWS_V2"] = "1"
-    try:
+    with engine.option("v2", 1):
         rc, blocks, threads, lds = engine.grid(desc, rows * k_avg)
-    finally:
-        os.environ.pop("RTLWS_V2", None)
     assert (rc, threads) == (0, 128) and lds == 8 * (15 * 290 + 15 * 18 + 18) and blocks <= 4 * 256
     a, b = _both(engine, iq, k_avg=k_avg, window=window, output=output)
     assert a.shape == (rows, 4096)
@@ -68,11 +60,8 @@ def test_v2_2048_bit_identical_to_the_two_wavefront_kernel(engine, built, oracle
     iq[5] = 128
     iq[7] = synth.uniform_iq(1, 2048, seed=3)[0]
     desc = built.make_desc(2048, k_avg, "cu8", window, output)
-    os.environ["RTLWS_V2"] = "1"
-    try:
+    with engine.option("v2", 1):
         rc, blocks, threads, lds = engine.grid(desc, rows * k_avg)
-    finally:
-        os.environ.pop("RTLWS_V2", None)
     assert (rc, threads) == (0, 64) and lds == 8 * 2334 and blocks <= 8 * 256
     a, b = _both(engine, iq, 2048, k_avg=k_avg, window=window, output=output)
     assert a.shape == (rows, 2048) and np.array_equal(a, b, equal_nan=True)

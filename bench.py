@@ -650,6 +650,53 @@ def realtime_main(args):
     return 0 if (r["chunks_dropped"] == 0 and r["chunks_failed"] == 0) else 5
 
 
+MULTI_BATCH_WORKLOAD = "multi_batch"
+
+
+def multi_batch_main(args):
+    """--workload multi_batch: BASELINE.json configs[1] sharded over the devices of the node by the
+    C host itself (rtl-ws_amd/lib/rtlws_multi_batch over include/rtlws_multi.h: one batch of
+    65 536 x G frames, shard g = rows [g*R/G, (g+1)*R/G) on device g, one host pthread + one engine
+    per device, per-device HIP-event times, no collective) -- the same measurement as the default
+    line without torch.distributed in the way.  --gpus N uses the first N devices (default: all)."""
+    import rtlws
+    exe = os.path.join(rtlws.LIB_DIR, "rtlws_multi_batch")
+    if not os.path.exists(exe):
+        rtlws.build()
+    ndev = rtlws.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    use = args.gpus if args.gpus > 1 else ndev
+    if use > ndev:
+        print("bench.py: --gpus %d but this host has %d HIP device(s)" % (use, ndev), file=sys.stderr)
+        return 2
+    per_gpu = args.frames if args.frames > 0 else WORKLOADS[HEADLINE][5]
+    cmd = [exe, "--frames", str(per_gpu * use), "--launches", str(args.steps), "--warmup", str(max(args.warmup, SETTLE_LAUNCHES)),
+           "--devices", str(use)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        sys.stderr.write(out.stderr)
+        return out.returncode
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    worst = max(s["event_ms_per_launch"] for s in r["per_shard"])
+    bytes_per_dev = r["algorithmic_bytes_per_frame"] * per_gpu
+    achieved = bytes_per_dev / (worst * 1e-3) / 1e9
+    line = {"metric": "spectra/s (1024-pt IQ frames)", "value": r["spectra_per_s_total"], "unit": "spectra/s",
+            "n_gpus": r["shards"], "steps": args.steps, "warmup": r["warmup"], "ms_per_step": r["wall_ms"] / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": MULTI_BATCH_WORKLOAD, "n_fft": r["n_fft"], "k_avg": r["k_avg"],
+                       "frames_per_step": r["frames_used"], "frames_per_gpu": per_gpu,
+                       "sharding": "C host: shard g = rows [g*R/G, (g+1)*R/G) on device g, one pthread + one engine "
+                                   "per device, no collective (include/rtlws_multi.h)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_clock": "hip_events_per_device_slowest_shard",
+                         "traffic": None, "algorithmic_bytes_per_launch": bytes_per_dev,
+                         "avg_launch_us": 1e3 * worst},
+            "per_device": r["per_shard"]}
+    print(json.dumps(strict_json(line), allow_nan=False), flush=True)
+    return 0
+
+
 def plumbing_main(args):
     """--plumbing-cpu (tests only): the rank plumbing of this file with the GPU step
     replaced by a sleep -- rendezvous over gloo, barrier-bracketed timing, MAX over
@@ -687,7 +734,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500,
                     help="untimed launches first; the clock governor needs ~300 (25 ms) to settle at the power cap")
-    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS) + [REALTIME_WORKLOAD])
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS) + [REALTIME_WORKLOAD, MULTI_BATCH_WORKLOAD])
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets")
     ap.add_argument("--input", default="tone", choices=["tone", "uniform"],
                     help="synthetic IQ: tone + noise (SURVEY.md 8d, default) or uniform random bytes")
@@ -699,6 +746,8 @@ def main(argv=None):
 
     if args.workload == REALTIME_WORKLOAD:          # one process drives every device (threads, no ranks)
         return realtime_main(args)
+    if args.workload == MULTI_BATCH_WORKLOAD:       # ... and so does the C batch driver
+        return multi_batch_main(args)
     if needs_fan_out(args.gpus, os.environ):
         return fan_out(args.gpus, argv, args.plumbing_cpu)
     if args.plumbing_cpu:

@@ -170,6 +170,12 @@ typedef struct rtlws_spectra_desc {
  * where the f32 transform of rtlws_spectra_batch holds 1e-4 only within 50 dB of a row's
  * maximum.  No effect on RTLWS_OUT_PAYLOAD_U8 (bytes either way) or on rtlws_spectra_batch. */
 #define RTLWS_FLAG_ROWS_F32 1
+/* rtlws_stream.h only (a stream has ONE entry point for both arithmetics): transform this
+ * stream's chunks with rtlws_spectra_batch_f64 -- the reference's own precision for a live
+ * sensor (src/signal_source.c:29-35 -> src/cbb_main.c:52-59).  Rows are then doubles, or floats
+ * with RTLWS_FLAG_ROWS_F32 as well.  Ignored by rtlws_spectra_batch / rtlws_spectra_batch_f64,
+ * where the function called IS the choice. */
+#define RTLWS_FLAG_F64 2
 
 /* Precision: f32 arithmetic (inputs are exact in f32; twiddles are f64-computed and
  * rounded once).  Against an f64 evaluation: power within 1e-4 relative for every

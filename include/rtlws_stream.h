@@ -28,8 +28,9 @@ typedef struct rtlws_stream rtlws_stream;
 
 /* Called on the stream's worker thread, in push order, once a chunk's results
  * are in host memory (a chunk whose device work failed is counted in
- * chunks_failed and NOT delivered).  `rows` points at rows_in_chunk * n_fft outputs (f32, or
- * bytes for RTLWS_OUT_PAYLOAD_U8) valid only during the call. */
+ * chunks_failed and NOT delivered).  `rows` points at rows_in_chunk * n_fft outputs (f32; bytes
+ * for RTLWS_OUT_PAYLOAD_U8; f64 for a stream opened with desc->flags & RTLWS_FLAG_F64 and without
+ * RTLWS_FLAG_ROWS_F32) valid only during the call. */
 typedef void (*rtlws_stream_callback)(const void* rows, long nrows, long first_frame,
                                       double latency_ms, void* user);
 
@@ -45,7 +46,11 @@ typedef struct rtlws_stream_stats {
 } rtlws_stream_stats;
 
 /* frames_per_chunk must be a multiple of desc->k_avg; ring_slots >= 2 chunks may
- * be in flight.  NULL on failure (rtlws_last_error). */
+ * be in flight.  desc->flags selects the arithmetic: 0 = the f32 fused kernel (rtlws_spectra_batch),
+ * RTLWS_FLAG_F64 = the reference's f64 (rtlws_spectra_batch_f64; + RTLWS_FLAG_ROWS_F32: f32 rows).
+ * Opening a stream also warms it: tables built, code object loaded, one chunk of mid-scale samples
+ * through every ring slot, so the first real chunk has the latency of any other.
+ * NULL on failure (rtlws_last_error). */
 rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
                                 int ring_slots, rtlws_stream_callback cb, void* user);
 

@@ -92,13 +92,15 @@ __global__ __launch_bounds__(256) void cicr_kernel(const uint8_t* __restrict__ s
     }
 }
 
+// cus: compute units of the engine's device (the grids are persistent: a few workgroups per CU)
 hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d_dst,
-                                 hipStream_t st)
+                                 hipStream_t st, int cus)
 {
     if (dst_len <= 0) return hipSuccess;
+    if (cus < 1) cus = 1;
     if (R == 8) {
         long blocks = (dst_len + 255) / 256;
-        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks > (long)cus * 8) blocks = (long)cus * 8;
         hipLaunchKernelGGL(cic8_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
                            reinterpret_cast<const nt_u4*>(d_src), reinterpret_cast<nt_i2*>(d_dst),
                            dst_len);
@@ -111,7 +113,7 @@ hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d
         const int G = slice / chunk;
         const long rounds = (dst_len / 64 + G - 1) / G;
         long blocks = (rounds + 3) / 4;
-        const long cap = 256L * (slice == 8192 ? 4 : 2);
+        const long cap = (long)cus * (slice == 8192 ? 4 : 2);
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         const uint8_t* s8 = reinterpret_cast<const uint8_t*>(d_src);
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(256) void fm_demod_kernel(const int2* __restrict__ 
 }
 
 hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
-                           float* d_out, hipStream_t st)
+                           float* d_out, hipStream_t st, int cus)
 {
     if (len <= 0) return hipSuccess;
+    if (cus < 1) cus = 1;
     long blocks = (len + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > (long)cus * 8) blocks = (long)cus * 8;
     hipLaunchKernelGGL(fm_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
                        reinterpret_cast<const int2*>(d_iq), len, d_prev_in, d_prev_out, d_out);
     return hipGetLastError();
@@ -212,11 +215,12 @@ __global__ __launch_bounds__(256) void halfband_kernel(const float* __restrict__
     }
 }
 
-hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t st)
+hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t st, int cus)
 {
     if (out_len <= 0) return hipSuccess;
+    if (cus < 1) cus = 1;
     long blocks = (out_len + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > (long)cus * 8) blocks = (long)cus * 8;
     hipLaunchKernelGGL(halfband_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_x, d_y, out_len);
     return hipGetLastError();
 }

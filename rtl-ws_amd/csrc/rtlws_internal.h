@@ -235,10 +235,10 @@ hipError_t launch_spectra_fused_2048(const SpectraParams&, int in_kind, int bloc
 hipError_t launch_spectra_fused_4096(const SpectraParams&, int in_kind, int blocks, hipStream_t);
 hipError_t launch_spectra_direct(const SpectraParams&, int in_kind, hipStream_t);
 
-hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d_dst, hipStream_t);
-hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t);
+hipError_t launch_cic_block_sums(int R, const void* d_src, long dst_len, void* d_dst, hipStream_t, int cus);
+hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream_t, int cus);
 hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
-                           float* d_out, hipStream_t);
+                           float* d_out, hipStream_t, int cus);
 hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t);
 hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t, int device);
 hipError_t launch_welch_accumulate(double* d_acc, const double* d_part, int n, long frames_end, double* d_b, hipStream_t);

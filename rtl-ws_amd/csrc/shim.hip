@@ -450,7 +450,10 @@ void rtlws_dev_free(rtlws_engine* e, void* dptr)
 void* rtlws_pinned_alloc(size_t bytes)
 {
     void* p = nullptr;
-    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), nullptr);
+    // Portable | Mapped, explicitly: the zero-copy paths have kernels of ANY engine's device read
+    // and write these buffers (stream rows, the drop-in staging buffers), whatever device was
+    // current on the allocating thread
+    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped), nullptr);
     return p;
 }
 
@@ -776,7 +779,7 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     // keeps everything on the row-per-workgroup kernel (A/B runs, tests)
     if (rtlws::f64_fused_kind(d->n_fft, in_kind) && e->opt.f64_fused && aligned) {
         int per_cu = rtlws::f64_fused_blocks_per_cu(d->n_fft);
-        if (e->opt.f64_blocks_per_cu > 0 && e->opt.f64_blocks_per_cu <= per_cu + 1) per_cu = e->opt.f64_blocks_per_cu;
+        if (e->opt.f64_blocks_per_cu > 0 && e->opt.f64_blocks_per_cu <= 2 * per_cu) per_cu = e->opt.f64_blocks_per_cu;   // experiments only
         long blocks = (long)e->cu_count * per_cu;
         if (blocks > p.ngroups) blocks = p.ngroups;
         switch (d->n_fft) {
@@ -852,7 +855,7 @@ int rtlws_cic_block_sums(rtlws_engine* e, int R, const void* d_src, long dst_len
         return -1;
     }
     HIP_TRY(hipSetDevice(e->device), -3);
-    hipError_t err = rtlws::launch_cic_block_sums(R, d_src, dst_len, d_dst, pick_stream(e, stream));
+    hipError_t err = rtlws::launch_cic_block_sums(R, d_src, dst_len, d_dst, pick_stream(e, stream), e->cu_count);
     if (err != hipSuccess) {
         set_err("cic kernel launch", err);
         return -3;
@@ -879,7 +882,7 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_p
                                pick_stream(e, stream)), -3);
         return 0;
     }
-    hipError_t err = rtlws::launch_fm_demod(d_iq, len, d_prev_in, d_prev_out, d_out, pick_stream(e, stream));
+    hipError_t err = rtlws::launch_fm_demod(d_iq, len, d_prev_in, d_prev_out, d_out, pick_stream(e, stream), e->cu_count);
     if (err != hipSuccess) {
         set_err("fm_demod kernel launch", err);
         return -3;
@@ -903,7 +906,7 @@ int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, 
         return -1;
     }
     HIP_TRY(hipSetDevice(e->device), -3);
-    hipError_t err = rtlws::launch_halfband(d_x, d_y, out_len, pick_stream(e, stream));
+    hipError_t err = rtlws::launch_halfband(d_x, d_y, out_len, pick_stream(e, stream), e->cu_count);
     if (err != hipSuccess) {
         set_err("halfband kernel launch", err);
         return -3;

@@ -49,15 +49,15 @@ void audio_init(void)
     pthread_mutex_lock(&g_mu);
     if (!g_eng) {
         g_eng = rtlws_engine_create(rtlws_host_device());
-        if (!g_eng) {
-            fprintf(stderr, "rtlws: audio_init: %s\n", rtlws_last_error());
-            abort();                  /* no CPU path */
+        if (!g_eng) {                 /* no CPU path; inert audio side, failure recorded (rtlws_host.h) */
+            rtlws_host_fail("audio_init", rtlws_last_error());
+        } else {
+            g_d_phase = (float*)rtlws_dev_alloc(g_eng, 2 * sizeof(float));
+            rtlws_memset_dev(g_eng, g_d_phase, 0, 2 * sizeof(float), NULL);
+            rtlws_stream_sync(g_eng, NULL);
+            g_len = 0;
+            g_phase_idx = 0;
         }
-        g_d_phase = (float*)rtlws_dev_alloc(g_eng, 2 * sizeof(float));
-        rtlws_memset_dev(g_eng, g_d_phase, 0, 2 * sizeof(float), NULL);
-        rtlws_stream_sync(g_eng, NULL);
-        g_len = 0;
-        g_phase_idx = 0;
     }
     /* a second audio_init without audio_close only restarts the queue: the phase
      * carry, the delay lines and the block length are function statics in the
@@ -128,7 +128,11 @@ void audio_fm_demodulator(const cmplx_s32* signal, int len)
     int rc = 0, have_buf;
     if (len <= 0) return;
     pthread_mutex_lock(&g_mu);
-    if (!g_eng) { pthread_mutex_unlock(&g_mu); fprintf(stderr, "rtlws: audio_fm_demodulator before audio_init\n"); abort(); }
+    if (!g_eng) {                     /* before audio_init, or audio_init found no device: nothing is queued */
+        pthread_mutex_unlock(&g_mu);
+        rtlws_host_fail("audio_fm_demodulator", "no engine (audio_init not called, or no usable HIP device)");
+        return;
+    }
     if (g_len != len) {
         float hist1[HIST], hist2[HIST];
         int have = g_len > 0;
@@ -168,10 +172,10 @@ void audio_fm_demodulator(const cmplx_s32* signal, int len)
         else
             g_phase_idx = 1 - g_phase_idx;
     }
-    if (rc) {
+    if (rc) {                         /* void signature: the block yields no audio, the failure is recorded */
         pthread_mutex_unlock(&g_mu);
-        fprintf(stderr, "rtlws: audio_fm_demodulator: device failure: %s\n", rtlws_last_error());
-        abort();                      /* void signature: fail loudly */
+        rtlws_host_fail("audio_fm_demodulator", rtlws_last_error());
+        return;
     }
     if (have_buf && quarter > 0) {
         float* dst = g_pool[(g_q_head + g_q_count) % AUDIO_BUFFER_POOL];

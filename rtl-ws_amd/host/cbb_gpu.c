@@ -94,6 +94,7 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
     rtlws_spectra_desc d;
 
     const int due = now_ms() >= g_last_est_ms + SPECTRUM_EST_MS;  /* :46-47 */
+    if (!g_eng) return;                          /* cbb_init found no device: inert (rtlws_host.h) */
     if (!due && !g_welch) return;
     blocks = blocks <= g_max_blocks ? blocks : g_max_blocks;     /* :49 (6 unless ALL_FRAMES) */
 
@@ -157,6 +158,32 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
     pthread_mutex_unlock(&g_mu);
 }
 
+/* everything cbb_init created on the device side (also the way out of a failed cbb_init) */
+static void free_engine_side(void)
+{
+    int k;
+    if (!g_eng) return;
+    rtlws_stream_sync(g_eng, NULL);
+    rtlws_dev_free(g_eng, g_d_iq);
+    rtlws_dev_free(g_eng, g_d_work);
+    rtlws_dev_free(g_eng, g_d_pub);
+    rtlws_dev_free(g_eng, g_d_payload);
+    rtlws_dev_free(g_eng, g_d_acc);
+    rtlws_dev_free(g_eng, g_d_b);
+    g_d_iq = g_d_payload = NULL;
+    g_d_work = g_d_pub = g_d_acc = g_d_b = NULL;
+    for (k = 0; k < IQ_SLOTS; ++k) {
+        rtlws_pinned_free(g_h_iq[k]);
+        rtlws_event_destroy(g_iq_done[k]);
+        g_h_iq[k] = NULL;
+        g_iq_done[k] = NULL;
+    }
+    rtlws_pinned_free(g_h_payload);
+    g_h_payload = NULL;
+    rtlws_engine_destroy(g_eng);                                  /* replaces spectrum_free, :145 */
+    g_eng = NULL;
+}
+
 void cbb_init(int decimated_bw_target_hz)
 {
     rtl_init(&g_dev, DEV_INDEX);                                  /* :77 */
@@ -166,10 +193,9 @@ void cbb_init(int decimated_bw_target_hz)
                                 (int)(rtl_sample_rate(g_dev) / (uint32_t)decimated_bw_target_hz));
 
     g_eng = rtlws_engine_create(rtlws_host_device());             /* replaces spectrum_alloc, :83 */
-    if (!g_eng) {
-        fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
-        abort();                                /* no CPU path to fall back to */
-    }
+    if (!g_eng)                                 /* no CPU path to fall back to, and no reason to */
+        rtlws_host_fail("cbb_init", rtlws_last_error());      /* take the server down: inert spectrum side */
+    if (g_eng) {
     {   /* the reference transforms 6 of the ~128 frames a sensor
          * buffer carries (:46-49); with RTLWS_CBB_ALL_FRAMES=1 the same launch averages
          * all of them (K = len/1024) -- same payload format, smoother spectrum */
@@ -198,8 +224,9 @@ void cbb_init(int decimated_bw_target_hz)
     g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
     if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_d_acc || !g_d_b || !g_h_iq[0] || !g_h_iq[1] ||
         !g_iq_done[0] || !g_iq_done[1] || !g_h_payload) {
-        fprintf(stderr, "rtlws: cbb_init: %s\n", rtlws_last_error());
-        abort();
+        rtlws_host_fail("cbb_init", rtlws_last_error());
+        free_engine_side();                     /* inert, as without a device */
+    }
     }
     g_pub_count = 0;
     g_last_est_ms = 0;
@@ -245,28 +272,7 @@ void cbb_close(void)
     rf_decimator_free(g_decim);                                   /* :143 */
     g_decim = NULL;
     pthread_mutex_lock(&g_mu);
-    if (g_eng) {
-        rtlws_dev_free(g_eng, g_d_iq);
-        rtlws_dev_free(g_eng, g_d_work);
-        rtlws_dev_free(g_eng, g_d_pub);
-        rtlws_dev_free(g_eng, g_d_payload);
-        rtlws_dev_free(g_eng, g_d_acc);
-        rtlws_dev_free(g_eng, g_d_b);
-        g_d_acc = g_d_b = NULL;
-        {
-            int k;
-            rtlws_stream_sync(g_eng, NULL);
-            for (k = 0; k < IQ_SLOTS; ++k) {
-                rtlws_pinned_free(g_h_iq[k]);
-                rtlws_event_destroy(g_iq_done[k]);
-                g_h_iq[k] = NULL;
-                g_iq_done[k] = NULL;
-            }
-        }
-        rtlws_pinned_free(g_h_payload);
-        rtlws_engine_destroy(g_eng);                              /* replaces spectrum_free, :145 */
-        g_eng = NULL;
-    }
+    free_engine_side();
     g_pub_count = 0;
     pthread_mutex_unlock(&g_mu);
     rtl_close(g_dev);                                             /* :149 */

@@ -17,14 +17,48 @@ struct rtlws_host_ctx {
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static struct rtlws_host_ctx g_ctx;
 static int g_tried = 0;
+static int g_zero_copy = 1;
 
 /* The drop-in entry points hand over host buffers: by default the kernels read and write the
  * pinned (device-mapped) staging buffers themselves -- one launch and one synchronisation per
- * call; RTLWS_DROPIN_ZEROCOPY=0 puts an H2D and a D2H copy around the launch instead (A/B). */
-static int zero_copy(void)
+ * call; RTLWS_DROPIN_ZEROCOPY=0 puts an H2D and a D2H copy around the launch instead (A/B).
+ * Read once, when the context is created; the device staging buffers exist only in that mode. */
+static int zero_copy(void) { return g_zero_copy; }
+
+/* ---- sticky failure record (include/rtlws_host.h) ---------------------- */
+static pthread_mutex_t g_err_mu = PTHREAD_MUTEX_INITIALIZER;
+static char g_err_first[320];
+static long g_err_count = 0;
+
+void rtlws_host_fail(const char* where, const char* what)
 {
-    const char* z = getenv("RTLWS_DROPIN_ZEROCOPY");
-    return !(z && z[0] == '0');
+    long n;
+    pthread_mutex_lock(&g_err_mu);
+    n = ++g_err_count;
+    if (n == 1) snprintf(g_err_first, sizeof g_err_first, "%s: %s", where, what ? what : "");
+    pthread_mutex_unlock(&g_err_mu);
+    if (n == 1 || n % 1024 == 0)
+        fprintf(stderr, "rtlws: %s: %s (failure %ld; no CPU path: the output of this call is zeros / empty)\n",
+                where, what ? what : "", n);
+}
+
+const char* rtlws_host_error(void) { return g_err_first; }
+
+long rtlws_host_error_count(void)
+{
+    long n;
+    pthread_mutex_lock(&g_err_mu);
+    n = g_err_count;
+    pthread_mutex_unlock(&g_err_mu);
+    return n;
+}
+
+void rtlws_host_error_clear(void)
+{
+    pthread_mutex_lock(&g_err_mu);
+    g_err_count = 0;
+    g_err_first[0] = 0;
+    pthread_mutex_unlock(&g_err_mu);
 }
 
 int rtlws_host_device(void)
@@ -38,6 +72,8 @@ struct rtlws_host_ctx* rtlws_host_ctx_get(void)
     struct rtlws_host_ctx* r = NULL;
     pthread_mutex_lock(&g_mu);
     if (!g_ctx.eng && !g_tried) {
+        const char* z = getenv("RTLWS_DROPIN_ZEROCOPY");
+        g_zero_copy = !(z && z[0] == '0');
         g_tried = 1;
         g_ctx.eng = rtlws_engine_create(rtlws_host_device());
         if (!g_ctx.eng)
@@ -88,8 +124,8 @@ int rtlws_host_cic(int R, const cmplx_u8* src, int src_len, cmplx_s32* dst, int 
     out_bytes = (size_t)dst_len * sizeof(cmplx_s32);
 
     pthread_mutex_lock(&g_mu);
-    if (grow_dev(c->eng, &c->d_in, &c->d_in_cap, in_bytes) ||
-        grow_dev(c->eng, &c->d_out, &c->d_out_cap, out_bytes) ||
+    if ((!zero_copy() && (grow_dev(c->eng, &c->d_in, &c->d_in_cap, in_bytes) ||
+                          grow_dev(c->eng, &c->d_out, &c->d_out_cap, out_bytes))) ||
         grow_pinned(&c->h_in, &c->h_in_cap, in_bytes) ||
         grow_pinned(&c->h_out, &c->h_out_cap, out_bytes)) {
         rc = -3;
@@ -135,6 +171,18 @@ int cic_decimate(int R, const cmplx_u8* src, int src_len, cmplx_s32* dst, int ds
     return rtlws_host_cic(R, src, src_len, dst, dst_len, delay);
 }
 
+/* the delay line becomes the last 10 samples of history + input (src/resample.c:66) */
+static void advance_delay(float* delay, const float* input, size_t n_in)
+{
+    const size_t keep = HALF_BAND_N - 1;
+    if (n_in >= keep) {
+        memcpy(delay, input + n_in - keep, keep * sizeof(float));
+    } else {
+        memmove(delay, delay + n_in, (keep - n_in) * sizeof(float));
+        memcpy(delay + keep - n_in, input, n_in * sizeof(float));
+    }
+}
+
 void halfband_decimate(const float* input, float* output, int output_len, float* delay)
 {
     struct rtlws_host_ctx* c = rtlws_host_ctx_get();
@@ -143,11 +191,18 @@ void halfband_decimate(const float* input, float* output, int output_len, float*
     const size_t out_bytes = (size_t)(output_len > 0 ? output_len : 0) * sizeof(float);
     int rc = 0;
     if (output_len <= 0) return;
-    if (!c) { fprintf(stderr, "rtlws: halfband_decimate: no device\n"); abort(); }
+    if (!c) {
+        /* the reference signature is void and there is no CPU path: silence out, the delay
+         * line advanced as src/resample.c:66 would, the failure recorded (rtlws_host.h) */
+        advance_delay(delay, input, n_in);
+        memset(output, 0, out_bytes);
+        rtlws_host_fail("halfband_decimate", "no usable HIP device");
+        return;
+    }
 
     pthread_mutex_lock(&g_mu);
-    if (grow_dev(c->eng, &c->d_in, &c->d_in_cap, in_bytes) ||
-        grow_dev(c->eng, &c->d_out, &c->d_out_cap, out_bytes) ||
+    if ((!zero_copy() && (grow_dev(c->eng, &c->d_in, &c->d_in_cap, in_bytes) ||
+                          grow_dev(c->eng, &c->d_out, &c->d_out_cap, out_bytes))) ||
         grow_pinned(&c->h_in, &c->h_in_cap, in_bytes) ||
         grow_pinned(&c->h_out, &c->h_out_cap, out_bytes)) {
         rc = -3;
@@ -172,8 +227,10 @@ void halfband_decimate(const float* input, float* output, int output_len, float*
     }
     pthread_mutex_unlock(&g_mu);
     if (rc) {
-        /* the reference signature is void: fail loudly rather than return garbage */
-        fprintf(stderr, "rtlws: halfband_decimate failed on the device: %s\n", rtlws_last_error());
-        abort();
+        /* the reference signature is void: a defined result (silence, delay line advanced
+         * from the inputs) and a recorded failure rather than garbage or a dead server */
+        advance_delay(delay, input, n_in);
+        memset(output, 0, out_bytes);
+        rtlws_host_fail("halfband_decimate", rtlws_last_error());
     }
 }

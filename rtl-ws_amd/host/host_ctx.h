@@ -7,7 +7,12 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "rtlws_hip.h"
+#include "rtlws_host.h"
 #include "resample.h"
+
+/* Record a failure of an entry point that cannot return one (include/rtlws_host.h):
+ * sticky first message, counter, stderr for the first and every 1024th. */
+void rtlws_host_fail(const char* where, const char* what);
 
 /* Device index used by the drop-in entry points: $RTLWS_DEVICE or 0. */
 int rtlws_host_device(void);

@@ -7,9 +7,12 @@
  *   rtlws_multi_stream [--streams S] [--seconds T] [--rate HZ | --unpaced]
  *                      [--nfft N] [--k K] [--output f32|db|payload]
  *                      [--chunk-buffers M] [--queues Q] [--plan-only --devices D]
+ *                      [--precision f32|f64|f64c_f32o]
  * Prints one JSON line: totals, and per stream its device, rate, drops and latency.
  *   --output payload   u8 rows (the 1024 bytes src/main.c:82 sends): 4x fewer D2H bytes
  *   --chunk-buffers M  M sensor buffers per chunk (unpaced throughput runs)
+ *   --precision        arithmetic of the streams: the f32 fused kernel (default), the reference's f64
+ *                      (rows of doubles), or f64 arithmetic with f32 rows (rtlws_stream.h, desc.flags)
  *   --plan-only        print the stream -> device plan for D devices and exit (no GPU needed)
  */
 #include <math.h>
@@ -41,7 +44,8 @@ static void on_rows(const void* rows, long nrows, long first_frame, double laten
     (void)first_frame; (void)latency_ms;
     /* touch the data like a consumer would */
     p->checksum += (p->desc.output == RTLWS_OUT_PAYLOAD_U8) ? (double)((const unsigned char*)rows)[0]
-                                                            : (double)((const float*)rows)[0];
+                   : ((p->desc.flags & RTLWS_FLAG_F64) && !(p->desc.flags & RTLWS_FLAG_ROWS_F32))
+                       ? ((const double*)rows)[0] : (double)((const float*)rows)[0];
     p->rows_seen += nrows;
 }
 
@@ -99,6 +103,8 @@ int main(int argc, char** argv)
     int streams = 8, nfft = 1024, k = 1, unpaced = 0, i, ndev, output = RTLWS_OUT_POWER_SUM;
     int chunk_buffers = 1, plan_only = 0, devices_override = 0, queues_override = 0;
     const char* output_name = "f32";
+    const char* precision = "f32";
+    int flags = 0;
     double seconds = 3.0, rate = 2400000.0;
     struct producer* ps;
     pthread_t* th;
@@ -115,6 +121,13 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--plan-only")) plan_only = 1;
         else if (!strcmp(argv[i], "--queues") && i + 1 < argc) queues_override = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_override = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--precision") && i + 1 < argc) {
+            precision = argv[++i];
+            if (!strcmp(precision, "f32")) flags = 0;
+            else if (!strcmp(precision, "f64")) flags = RTLWS_FLAG_F64;
+            else if (!strcmp(precision, "f64c_f32o")) flags = RTLWS_FLAG_F64 | RTLWS_FLAG_ROWS_F32;
+            else { fprintf(stderr, "--precision f32|f64|f64c_f32o\n"); return 2; }
+        }
         else if (!strcmp(argv[i], "--output") && i + 1 < argc) {
             output_name = argv[++i];
             if (!strcmp(output_name, "f32")) output = RTLWS_OUT_POWER_SUM;
@@ -154,6 +167,7 @@ int main(int argc, char** argv)
         ps[i].desc.input = RTLWS_IN_CU8;
         ps[i].desc.window = RTLWS_WIN_RECT;
         ps[i].desc.output = output;
+        ps[i].desc.flags = flags;
         pthread_create(&th[i], NULL, producer_main, &ps[i]);
     }
     for (i = 0; i < streams; i++) pthread_join(th[i], NULL);
@@ -166,11 +180,11 @@ int main(int argc, char** argv)
         if (ps[i].stats.latency_ms_max > lat_max) lat_max = ps[i].stats.latency_ms_max;
     }
     printf("{\"streams\": %d, \"devices\": %d, \"paced\": %s, \"rate_hz\": %.0f, \"n_fft\": %d, \"k_avg\": %d, "
-           "\"output\": \"%s\", \"chunk_buffers\": %d, "
+           "\"output\": \"%s\", \"precision\": \"%s\", \"chunk_buffers\": %d, "
            "\"seconds\": %.2f, \"spectra_per_s_total\": %.1f, \"spectra_per_s_per_stream\": %.1f, "
            "\"frames_done\": %ld, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, \"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f, "
            "\"per_stream\": [",
-           streams, ndev, unpaced ? "false" : "true", rate, nfft, k, output_name, chunk_buffers, seconds, total_rate,
+           streams, ndev, unpaced ? "false" : "true", rate, nfft, k, output_name, precision, chunk_buffers, seconds, total_rate,
            total_rate / streams, frames, drops, failed, lat_avg, lat_max);
     for (i = 0; i < streams; i++)
         printf("%s{\"stream\": %d, \"device\": %d, \"queues\": %d, \"spectra_per_s\": %.1f, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, "

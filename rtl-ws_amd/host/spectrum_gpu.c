@@ -23,8 +23,8 @@
 struct spectrum {
     int N;
     rtlws_engine* eng;
-    void* d_in;       /* N * 8 bytes: large enough for cmplx_s32 */
-    double* d_out;    /* N doubles */
+    void* d_in;       /* N * 8 bytes: large enough for cmplx_s32 (NULL in zero-copy mode) */
+    double* d_out;    /* N doubles (NULL in zero-copy mode) */
     void* h_in;       /* pinned */
     double* h_out;    /* pinned */
     int zero_copy;
@@ -50,15 +50,17 @@ struct spectrum* spectrum_alloc(int N)
         free(s);
         return NULL;
     }
-    s->d_in = rtlws_dev_alloc(s->eng, (size_t)N * sizeof(cmplx_s32));
-    s->d_out = (double*)rtlws_dev_alloc(s->eng, (size_t)N * sizeof(double));
-    s->h_in = rtlws_pinned_alloc((size_t)N * sizeof(cmplx_s32));
-    s->h_out = (double*)rtlws_pinned_alloc((size_t)N * sizeof(double));
     {
         const char* z = getenv("RTLWS_DROPIN_ZEROCOPY");
         s->zero_copy = !(z && z[0] == '0');
     }
-    if (!s->d_in || !s->d_out || !s->h_in || !s->h_out) {
+    if (!s->zero_copy) {             /* device staging exists only in the two-copies mode */
+        s->d_in = rtlws_dev_alloc(s->eng, (size_t)N * sizeof(cmplx_s32));
+        s->d_out = (double*)rtlws_dev_alloc(s->eng, (size_t)N * sizeof(double));
+    }
+    s->h_in = rtlws_pinned_alloc((size_t)N * sizeof(cmplx_s32));
+    s->h_out = (double*)rtlws_pinned_alloc((size_t)N * sizeof(double));
+    if ((!s->zero_copy && (!s->d_in || !s->d_out)) || !s->h_in || !s->h_out) {
         fprintf(stderr, "rtlws: spectrum_alloc: %s\n", rtlws_last_error());
         spectrum_free(s);
         return NULL;

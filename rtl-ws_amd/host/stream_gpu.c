@@ -13,7 +13,7 @@
  * How many queues (measured with rows copied back by the copy engine, one MI355X, 128-frame
  * chunks, profiles/r03_multi_stream_experiments.txt; the kernel now stores rows into the pinned
  * slot itself, see rtlws_stream_open_q):
- *   one sensor on the device      1 queue 2.5e6 spectra/s, 4 queues 4.7e6 (+88 %)
+ *   one sensor on the device      1 queue 2.56e6 spectra/s, 4 queues 4.81e6 (+88 %)
  *   four / eight sensors          1 queue EACH 6.9e6 / 5.9e6; 4 each 5.5e6 / 3.8e6 (32 HIP
  *                                 streams oversubscribe the hardware queues); a shared pool of
  *                                 4 or 8 queues 4.3-5.3e6; copy-in / transform / copy-out
@@ -34,8 +34,8 @@ enum { SLOT_FREE = 0, SLOT_IN_FLIGHT = 1 };
 struct slot {
     void* h_in;      /* pinned */
     void* h_out;     /* pinned */
-    void* d_in;
-    void* d_out;
+    void* d_in;      /* device staging of the input (NULL when the kernel reads the pinned slot) */
+    void* d_out;     /* device staging of the rows (NULL when the kernel stores into the pinned slot) */
     void* q;         /* this slot's in-order queue (NULL: the engine's own) */
     void* done;      /* recorded after the D2H copy; the worker sleeps on it */
     int state;
@@ -62,6 +62,7 @@ struct rtlws_stream {
     pthread_mutex_t mu;
     pthread_cond_t cv_work, cv_free;
     int closing;
+    int worker_ready;                /* the worker thread has made its first HIP call */
     rtlws_stream_stats st;
     double lat_sum;
 };
@@ -89,9 +90,37 @@ static size_t sample_bytes(const rtlws_spectra_desc* d)
     }
 }
 
+/* bytes of one output value: payload bytes, f64 rows (RTLWS_FLAG_F64 without
+ * RTLWS_FLAG_ROWS_F32), f32 rows otherwise */
+static size_t out_elem_bytes(const rtlws_spectra_desc* d)
+{
+    if (d->output == RTLWS_OUT_PAYLOAD_U8) return 1;
+    return ((d->flags & RTLWS_FLAG_F64) && !(d->flags & RTLWS_FLAG_ROWS_F32)) ? 8 : 4;
+}
+
+/* copy in, transform, copy out, mark: in program order on this slot's queue */
+static int enqueue_chunk(rtlws_stream* s, struct slot* sl)
+{
+    const void* in = s->zero_copy_in ? sl->h_in : sl->d_in;
+    void* out = s->zero_copy_out ? sl->h_out : sl->d_out;
+    return (!s->zero_copy_in && rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, sl->q)) ||
+           ((s->desc.flags & RTLWS_FLAG_F64)      /* the reference's arithmetic (src/spectrum.c:54-60,21,28) */
+                ? rtlws_spectra_batch_f64(s->eng, &s->desc, in, s->frames_per_chunk, out, sl->q)
+                : rtlws_spectra_batch(s->eng, &s->desc, in, s->frames_per_chunk, out, sl->q)) ||
+           (!s->zero_copy_out && rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, sl->q)) ||
+           rtlws_event_record(sl->done, s->eng, sl->q);
+}
+
 static void* worker_main(void* arg)
 {
     rtlws_stream* s = (rtlws_stream*)arg;
+    /* A thread's first HIP call sets up its runtime state (milliseconds): make it now, on slot 0's
+     * already completed warm-start event, not on the first real chunk's. */
+    (void)rtlws_event_sync(s->slots[0].done);
+    pthread_mutex_lock(&s->mu);
+    s->worker_ready = 1;
+    pthread_cond_broadcast(&s->cv_free);
+    pthread_mutex_unlock(&s->mu);
     for (;;) {
         struct slot* sl;
         double lat;
@@ -156,8 +185,7 @@ rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, lo
     s->frames_per_chunk = frames_per_chunk;
     s->rows_per_chunk = frames_per_chunk / desc->k_avg;
     s->in_bytes = (size_t)frames_per_chunk * (size_t)desc->n_fft * sample_bytes(desc);
-    s->out_bytes = (size_t)s->rows_per_chunk * (size_t)desc->n_fft *
-                   (desc->output == RTLWS_OUT_PAYLOAD_U8 ? 1u : 4u);
+    s->out_bytes = (size_t)s->rows_per_chunk * (size_t)desc->n_fft * out_elem_bytes(desc);
     s->nslots = ring_slots;
     s->cb = cb;
     s->user = user;
@@ -190,17 +218,35 @@ rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, lo
             s->nq = i + 1;
         }
     }
+    {
+        /* the worker sleeps on the event, it does not spin (RTLWS_STREAM_SPIN=1: it spins; A/B) */
+        const char* sp = getenv("RTLWS_STREAM_SPIN");
+        const int spin = sp && sp[0] == '1';
+        for (i = 0; i < ring_slots; i++) {
+            struct slot* sl = &s->slots[i];
+            sl->q = s->nq ? s->q[i % s->nq] : NULL;
+            sl->h_in = rtlws_pinned_alloc(s->in_bytes);
+            sl->h_out = rtlws_pinned_alloc(s->out_bytes);
+            /* device staging only for the side that is not zero-copy */
+            if (!s->zero_copy_in) sl->d_in = rtlws_dev_alloc(s->eng, s->in_bytes);
+            if (!s->zero_copy_out) sl->d_out = rtlws_dev_alloc(s->eng, s->out_bytes);
+            sl->done = spin ? rtlws_event_create() : rtlws_event_create_blocking();
+            if (!sl->h_in || !sl->h_out || (!s->zero_copy_in && !sl->d_in) || (!s->zero_copy_out && !sl->d_out) ||
+                !sl->done) {
+                rtlws_stream_close(s);
+                return NULL;
+            }
+        }
+    }
+    /* Warm start: one chunk of mid-scale samples through every slot's own chain, now.  The first
+     * launch of a process pays the code-object load and the twiddle-table upload, the first touch
+     * of a pinned slot its mapping -- 19-25 ms on the first buffers of three of eight sensors in
+     * round 3 (profiles/r03_multi_stream.jsonl, latency_ms_max), against 0.05-0.5 ms afterwards.
+     * Paid here, before the sensor starts, a latency budget never sees it. */
     for (i = 0; i < ring_slots; i++) {
         struct slot* sl = &s->slots[i];
-        sl->q = s->nq ? s->q[i % s->nq] : NULL;
-        sl->h_in = rtlws_pinned_alloc(s->in_bytes);
-        sl->h_out = rtlws_pinned_alloc(s->out_bytes);
-        sl->d_in = rtlws_dev_alloc(s->eng, s->in_bytes);
-        sl->d_out = rtlws_dev_alloc(s->eng, s->out_bytes);
-        /* the worker sleeps on the event, it does not spin (RTLWS_STREAM_SPIN=1: it spins; A/B) */
-        sl->done = (getenv("RTLWS_STREAM_SPIN") && getenv("RTLWS_STREAM_SPIN")[0] == '1') ? rtlws_event_create()
-                                                                                            : rtlws_event_create_blocking();
-        if (!sl->h_in || !sl->h_out || !sl->d_in || !sl->d_out || !sl->done) {
+        memset(sl->h_in, desc->input == RTLWS_IN_CU8 ? 128 : 0, s->in_bytes);
+        if (enqueue_chunk(s, sl) || rtlws_event_sync(sl->done)) {
             rtlws_stream_close(s);
             return NULL;
         }
@@ -209,6 +255,9 @@ rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, lo
         rtlws_stream_close(s);
         return NULL;
     }
+    pthread_mutex_lock(&s->mu);
+    while (!s->worker_ready) pthread_cond_wait(&s->cv_free, &s->mu);
+    pthread_mutex_unlock(&s->mu);
     return s;
 }
 
@@ -231,12 +280,7 @@ int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block)
     sl->first_frame = s->next_frame;
     sl->t_push_ms = now_ms();
     memcpy(sl->h_in, iq_host, s->in_bytes);
-    /* copy in, transform, copy out, mark: in program order on this slot's queue */
-    if ((!s->zero_copy_in && rtlws_copy_h2d(s->eng, sl->d_in, sl->h_in, s->in_bytes, sl->q)) ||
-        rtlws_spectra_batch(s->eng, &s->desc, s->zero_copy_in ? sl->h_in : sl->d_in, s->frames_per_chunk,
-                            s->zero_copy_out ? sl->h_out : sl->d_out, sl->q) ||
-        (!s->zero_copy_out && rtlws_copy_d2h(s->eng, sl->h_out, sl->d_out, s->out_bytes, sl->q)) ||
-        rtlws_event_record(sl->done, s->eng, sl->q)) {
+    if (enqueue_chunk(s, sl)) {
         /* part of the chain may already be queued against this slot's buffers, and
          * the slot stays FREE: drain the queue so that the next push cannot
          * overwrite h_in / d_in under a copy or a kernel still in flight */

@@ -30,6 +30,7 @@ IN_CU8, IN_CS32, IN_RF32 = 0, 1, 2
 WIN_RECT, WIN_HANN = 0, 1
 OUT_POWER_SUM, OUT_MEAN_DB, OUT_PAYLOAD_U8 = 0, 1, 2
 FLAG_ROWS_F32 = 1          # rtlws_spectra_batch_f64: f64 arithmetic, f32 rows
+FLAG_F64 = 2               # rtlws_stream.h: this stream computes in f64
 
 _INPUTS = {"cu8": IN_CU8, "cs32": IN_CS32, "rf32": IN_RF32}
 _WINDOWS = {"rect": WIN_RECT, "hann": WIN_HANN, None: WIN_RECT}
@@ -79,6 +80,14 @@ AMD_SYMBOLS = [
     "rf_decimator_add_callback", "rf_decimator_set_parameters", "rf_decimator_decimate_cmplx_u8",
     "rf_decimator_remove_callbacks", "rf_decimator_free",
 ]
+
+# include/rtlws_multi.h: one device-resident batch sharded over the devices of a node (librtlws_amd.so)
+MULTI_SYMBOLS = ["rtlws_multi_partition", "rtlws_multi_open", "rtlws_multi_shards", "rtlws_multi_frames",
+                 "rtlws_multi_frame_bytes", "rtlws_multi_row_bytes", "rtlws_multi_upload", "rtlws_multi_run",
+                 "rtlws_multi_download", "rtlws_multi_close"]
+
+# include/rtlws_host.h: sticky failure record of the void entry points (librtlws_amd.so)
+HOST_SYMBOLS = ["rtlws_host_error", "rtlws_host_error_count", "rtlws_host_error_clear"]
 
 CBB_SYMBOLS = ["cbb_init", "cbb_rf_decimator", "cbb_get_rtl_dev", "cbb_new_spectrum_available",
                "cbb_get_spectrum_payload", "cbb_close"]
@@ -188,12 +197,40 @@ def amd_lib():
         L.rf_decimator_decimate_cmplx_u8.restype = i
         L.rf_decimator_remove_callbacks.argtypes = [vp]
         L.rf_decimator_free.argtypes = [vp]
+        lp = C.POINTER(C.c_long)
+        L.rtlws_multi_partition.argtypes = [C.c_long, i, i, i, lp, lp]
+        L.rtlws_multi_open.argtypes = [i, C.POINTER(i), C.POINTER(SpectraDesc), C.c_long, i]
+        L.rtlws_multi_open.restype = vp
+        L.rtlws_multi_shards.argtypes = [vp]
+        L.rtlws_multi_frames.argtypes = [vp]
+        L.rtlws_multi_frames.restype = C.c_long
+        L.rtlws_multi_frame_bytes.argtypes = [vp]
+        L.rtlws_multi_frame_bytes.restype = C.c_size_t
+        L.rtlws_multi_row_bytes.argtypes = [vp]
+        L.rtlws_multi_row_bytes.restype = C.c_size_t
+        L.rtlws_multi_upload.argtypes = [vp, vp]
+        L.rtlws_multi_run.argtypes = [vp, i, vp, C.POINTER(C.c_double)]
+        L.rtlws_multi_download.argtypes = [vp, vp]
+        L.rtlws_multi_close.argtypes = [vp]
+        L.rtlws_host_error.restype = C.c_char_p
+        L.rtlws_host_error_count.restype = C.c_long
+        L.rtlws_host_error_clear.restype = None
         _amd = L
     return _amd
 
 
 def last_error():
     return hip_lib().rtlws_last_error().decode()
+
+
+def host_error():
+    """(count, first message) of include/rtlws_host.h's sticky failure record."""
+    L = amd_lib()
+    return L.rtlws_host_error_count(), L.rtlws_host_error().decode()
+
+
+def host_error_clear():
+    amd_lib().rtlws_host_error_clear()
 
 
 def device_count():
@@ -456,6 +493,71 @@ class RfDecimator:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+# ---- include/rtlws_multi.h ----------------------------------------------------
+
+class MultiShardStats(C.Structure):
+    _fields_ = [("device", C.c_int), ("first_frame", C.c_long), ("frames", C.c_long), ("launches", C.c_int),
+                ("event_ms", C.c_double), ("wall_ms", C.c_double), ("rc", C.c_int)]
+
+
+def multi_partition(nframes, k_avg, shards, g):
+    """rtlws_multi_partition: (rc, first_frame, frame_count).  No GPU needed."""
+    a, b = C.c_long(-1), C.c_long(-1)
+    rc = amd_lib().rtlws_multi_partition(int(nframes), int(k_avg), int(shards), int(g), C.byref(a), C.byref(b))
+    return rc, a.value, b.value
+
+
+class MultiBatch:
+    """rtlws_multi*: one batch sharded over devices (device_ids: one shard per entry; None = every device)."""
+
+    def __init__(self, desc, nframes, device_ids=None, f64=False):
+        L = amd_lib()
+        n = 0 if device_ids is None else len(device_ids)
+        ids = None if device_ids is None else (C.c_int * n)(*device_ids)
+        self.desc, self.f64 = desc, f64
+        self.h = L.rtlws_multi_open(n, ids, C.byref(desc), int(nframes), 1 if f64 else 0)
+        if not self.h:
+            raise RuntimeError("rtlws_multi_open failed: %s" % last_error())
+        self.shards = L.rtlws_multi_shards(self.h)
+        self.frames = L.rtlws_multi_frames(self.h)
+
+    def upload(self, frames):
+        frames = np.ascontiguousarray(frames)
+        assert frames.nbytes >= self.frames * amd_lib().rtlws_multi_frame_bytes(self.h)
+        rc = amd_lib().rtlws_multi_upload(self.h, _p(frames))
+        if rc:
+            raise RuntimeError("rtlws_multi_upload rc=%d: %s" % (rc, last_error()))
+
+    def run(self, launches=1):
+        st = (MultiShardStats * self.shards)()
+        wall = C.c_double(0.0)
+        rc = amd_lib().rtlws_multi_run(self.h, int(launches), st, C.byref(wall))
+        if rc:
+            raise RuntimeError("rtlws_multi_run rc=%d: %s" % (rc, last_error()))
+        return list(st), wall.value
+
+    def download(self):
+        rows = self.frames // self.desc.k_avg
+        rb = amd_lib().rtlws_multi_row_bytes(self.h)
+        dt = np.uint8 if self.desc.output == OUT_PAYLOAD_U8 else {4: np.float32, 8: np.float64}[rb // self.desc.n_fft]
+        out = np.empty((rows, self.desc.n_fft), dtype=dt)
+        rc = amd_lib().rtlws_multi_download(self.h, _p(out))
+        if rc:
+            raise RuntimeError("rtlws_multi_download rc=%d: %s" % (rc, last_error()))
+        return out
+
+    def close(self):
+        if self.h:
+            amd_lib().rtlws_multi_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(built):
     for name in declared_hip:
         assert hasattr(hip, name), "librtlws_hip.so lacks " + name
     declared_amd = []
-    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h", "audio_main.h"):
+    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h", "audio_main.h", "rtlws_host.h", "rtlws_multi.h"):
         fns = _declared_functions(h)
         assert fns, h
         declared_amd += fns
@@ -50,7 +50,8 @@ def test_every_declared_symbol_is_exported(built):
         assert hasattr(synth, name), "librtlws_synth.so lacks " + name
     # the binding's own lists agree with the headers
     assert set(built.HIP_SYMBOLS) == set(declared_hip)
-    assert set(built.AMD_SYMBOLS) | set(built.STREAM_SYMBOLS) | set(built.AUDIO_SYMBOLS) == set(declared_amd)
+    assert (set(built.AMD_SYMBOLS) | set(built.STREAM_SYMBOLS) | set(built.AUDIO_SYMBOLS) | set(built.HOST_SYMBOLS)
+            | set(built.MULTI_SYMBOLS) == set(declared_amd))
     assert set(built.CBB_SYMBOLS) == set(declared_cbb)
     assert set(built.SYNTH_SYMBOLS) == set(declared_synth)
 
@@ -81,6 +82,95 @@ def test_no_gpu_fails_loudly(built):
         built.Spectrum(1024)
     rc, _, _ = built.cic_decimate(8, np.zeros((64, 2), dtype=np.uint8))
     assert rc == -3
+
+
+def test_void_entry_points_do_not_kill_the_host_without_a_gpu(built):
+    """halfband_decimate / audio_* return void (src/resample.h:17, src/audio_main.c:53,106): with no
+    device they must not compute on the CPU -- and must not abort() the server they were dropped
+    into either: zeros out, delay line advanced as src/resample.c:66 would, failure recorded
+    (include/rtlws_host.h)."""
+    if built.device_count() > 0:
+        pytest.skip("a GPU is present")
+    built.host_error_clear()
+    assert built.host_error() == (0, "")
+    x = np.arange(1, 41, dtype=np.float32)
+    delay = np.full(10, 7.0, dtype=np.float32)
+    y = built.halfband_decimate(x, delay)
+    assert y.shape == (20,) and not y.any()                       # silence, not garbage, not a CPU filter
+    assert np.array_equal(delay, x[-10:])                         # the delay line still advances
+    short = np.array([1.0, 2.0], dtype=np.float32)
+    d2 = np.arange(10, dtype=np.float32)
+    built.halfband_decimate(short, d2)
+    assert np.array_equal(d2, np.array([2, 3, 4, 5, 6, 7, 8, 9, 1, 2], dtype=np.float32))
+    n, msg = built.host_error()
+    assert n == 2 and msg.startswith("halfband_decimate: ")       # sticky: the FIRST message, every failure counted
+    A = built.amd_lib()
+    A.audio_init()
+    buf = np.zeros((64, 2), dtype=np.int32)
+    A.audio_fm_demodulator(buf.ctypes.data_as(ctypes.c_void_p), 64)
+    assert A.audio_new_audio_available() == 0                     # nothing queued
+    A.audio_close()
+    n2, msg2 = built.host_error()
+    assert n2 == 4 and msg2 == msg
+    built.host_error_clear()
+    assert built.host_error() == (0, "")
+
+
+def _own_call_graph(lib):
+    """{function: set(call targets)} of a shared library's own .text (objdump -d; direct calls and
+    tail jumps to named symbols; PLT stubs keep their `name@plt` spelling)."""
+    import subprocess
+    txt = subprocess.run(["objdump", "-d", "--no-show-raw-insn", "-j", ".text", lib], capture_output=True, text=True,
+                         check=True).stdout
+    graph, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", line)
+        if m:
+            cur = m.group(1)
+            graph[cur] = set()
+            continue
+        if cur is None:
+            continue
+        m = re.search(r"\b(?:call|jmp|j[a-z]+)\s+[0-9a-f]+ <([^>+]+)(?:\+0x[0-9a-f]+)?>", line)
+        if m and m.group(1) != cur:
+            graph[cur].add(m.group(1))
+    return graph
+
+
+def _reaches(graph, start, target):
+    seen, todo = set(), [start]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for g in graph.get(f, ()):
+            if g == target:
+                return True
+            todo.append(g)
+    return False
+
+
+def test_no_launch_path_reads_the_environment(built):
+    """RTLWS_V2 / RTLWS_*BLOCKS_PER_CU / RTLWS_F64_FUSED / RTLWS_CIC_* were read
+    with getenv() on every launch.  They are now read ONCE, in rtlws_engine_create: in the built
+    library no call path from a launch entry point reaches getenv (call graph of the library's own
+    code, from its disassembly), while the one from rtlws_engine_create does (positive control)."""
+    g = _own_call_graph(built.HIP_LIB)
+    assert "rtlws_spectra_batch" in g and "rtlws_engine_create" in g
+    assert _reaches(g, "rtlws_engine_create", "getenv@plt")
+    for entry in ("rtlws_spectra_batch", "rtlws_spectra_batch_f64", "rtlws_cic_block_sums", "rtlws_halfband",
+                  "rtlws_fm_demod", "rtlws_payload_from_sums", "rtlws_payload_from_sums_f64",
+                  "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64", "rtlws_spectra_grid",
+                  "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_stream_sync", "rtlws_event_record"):
+        assert entry in g and g[entry], entry                     # the function exists and calls something
+        assert not _reaches(g, entry, "getenv@plt"), entry + " can reach getenv()"
+    # ... and in the C host layer the drop-in calls do not either (spectrum_alloc / the lazily
+    # created context read their switches once)
+    h = _own_call_graph(built.AMD_LIB)
+    assert _reaches(h, "spectrum_alloc", "getenv@plt")
+    for entry in ("spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32", "rtlws_stream_push"):
+        assert entry in h and not _reaches(h, entry, "getenv@plt"), entry
 
 
 def test_product_never_touches_the_oracle():

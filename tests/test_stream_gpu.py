@@ -33,21 +33,27 @@ def _lib(built):
     return L
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64", "f64c_f32o"])
 @pytest.mark.parametrize("K", [1, 8])
-def test_stream_results_in_order_and_equal_to_oracle(built, oracle, K):
+def test_stream_results_in_order_and_equal_to_oracle(built, oracle, K, prec):
+    """prec: the arithmetic of the stream (desc.flags): the f32 fused kernel, the reference's f64
+    with f64 rows (strict bound 1e-10), or f64 arithmetic with f32 rows (one f32 rounding)."""
     from rtlws import synth
     L = _lib(built)
     N, frames_per_chunk, nchunks = 1024, 128, 12
     iq = synth.tone_noise_iq(frames_per_chunk * nchunks, N, seed=K)
-    got, firsts = [], []
+    got, firsts, lats = [], [], []
+    ctype = C.c_double if prec == "f64" else C.c_float
 
     @CB
     def cb(rows, nrows, first_frame, lat, user):
-        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_float)), shape=(nrows, N))
+        a = np.ctypeslib.as_array(C.cast(rows, C.POINTER(ctype)), shape=(nrows, N))
         got.append(a.copy())
         firsts.append(first_frame)
+        lats.append(lat)
 
-    desc = built.make_desc(N, k_avg=K)
+    flags = {"f32": 0, "f64": built.FLAG_F64, "f64c_f32o": built.FLAG_F64 | built.FLAG_ROWS_F32}[prec]
+    desc = built.make_desc(N, k_avg=K, flags=flags)
     s = L.rtlws_stream_open(0, C.byref(desc), frames_per_chunk, 3, cb, None)
     assert s
     for c in range(nchunks):
@@ -61,7 +67,16 @@ def test_stream_results_in_order_and_equal_to_oracle(built, oracle, K):
     assert st.frames_done == frames_per_chunk * nchunks and st.latency_ms_max > 0
     assert firsts == [c * frames_per_chunk for c in range(nchunks)]
     ref = oracle.batch_spectra_u8(iq, N, K=K, nthreads=8)
-    assert rel_err(np.concatenate(got), ref, EPS_K1 if K == 1 else EPS_STRICT).max() <= TOL
+    rows = np.concatenate(got)
+    if prec == "f64":
+        assert rows.dtype == np.float64 and rel_err(rows, ref, EPS_STRICT).max() <= 1e-10
+    elif prec == "f64c_f32o":
+        assert rows.dtype == np.float32 and rel_err(rows, ref, EPS_STRICT).max() <= 6.0e-8
+    else:
+        assert rel_err(rows, ref, EPS_K1 if K == 1 else EPS_STRICT).max() <= TOL
+    # rtlws_stream_open warmed every slot (tables, code object, pinned mappings): the first real
+    # chunk is not an outlier (round 3: 19-25 ms on the first buffers)
+    assert lats[0] < 5.0 and max(lats) < 5.0, lats
 
 
 def test_stream_drops_when_ring_is_full_and_not_blocking(built):

@@ -92,6 +92,9 @@ struct SpectraParamsF64 {
     const double2* tw2f;     // [16][2] last-pass (cos, sin/cos) pairs
     const double2* hann_csf; // [64] (0.5*cos, 0.5*sin)(2*pi*t/N)
     int rows_f32;            // RTLWS_FLAG_ROWS_F32: f64 arithmetic, rows rounded once to f32 on the store
+    // spectrum_f64_1024x.hip (1024 = 4 x 16 x 16, one LDS transposition)
+    const double2* twxa;     // [4][8] (cos, tan) pairs of pass A's geometric pre-twiddle alpha = W_64^p
+    const double2* twxb;     // [64][16] W_1024^(c (4 q + p)) / 128, lane 16 p + c, slot s: q = rev16(s)
 };
 
 // which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip): the three
@@ -119,6 +122,8 @@ constexpr int f64_fused_lds_elems(int n_fft) { return 15 * 17 * (n_fft / 256) + 
 constexpr int f64_fused_lds_bytes(int n_fft) { return 16 * f64_fused_lds_elems(n_fft); }
 // 8 wavefronts per CU (2 per SIMD) at every size: 8 / 4 / 2 workgroups
 constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
+// rectangular 1024-point cmplx_u8 frames: the one-transposition kernel (engine option f64_x1024)
+hipError_t launch_spectra_f64_1024x(const SpectraParamsF64&, int blocks, hipStream_t);
 hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_2048(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);

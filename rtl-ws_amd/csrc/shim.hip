@@ -58,6 +58,8 @@ struct Tables {
     double2* tw1u_64 = nullptr;     //   ... unscaled (real f32 input)
     double2* tw2_64 = nullptr;      //   [16][R3/2] last-pass (cos, sin/cos) pairs
     double2* hann_cs64 = nullptr;   //   [T] (0.5 cos, 0.5 sin)(2 pi t / N)
+    double2* twxa_64 = nullptr;     // spectrum_f64_1024x.hip (N = 1024): [4][8] pass-A (cos, tan) pairs
+    double2* twxb_64 = nullptr;     //   [64][16] inner twiddles x lane constant / 128
 };
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;
@@ -72,6 +74,7 @@ struct EngineOpts {
     int blocks_per_cu = 0;       // RTLWS_BLOCKS_PER_CU: > 0 overrides the f32 fused kernels' grid
     int f64_fused = 1;           // RTLWS_F64_FUSED=0: f64 batches stay on the row-per-workgroup kernel
     int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
+    int f64_x1024 = 1;           // RTLWS_F64_X1024=0: rectangular 1024-point u8 frames stay on the two-transposition kernel
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
     int cic_round = 0;           // RTLWS_CIC_ROUND=1|2|4: LDS staging depth where R fits it
 };
@@ -132,6 +135,8 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.tw1u_64);
     (void)hipFree(tb.tw2_64);
     (void)hipFree(tb.hann_cs64);
+    (void)hipFree(tb.twxa_64);
+    (void)hipFree(tb.twxb_64);
     tb = Tables();
 }
 
@@ -272,6 +277,35 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
             free_tables(tb);
             return -3;
         }
+        if (n_fft == 1024) {
+            // spectrum_f64_1024x.hip: 1024 = 4 x 16 x 16.  Pass A (radix-16 over r on lane (p, c)) absorbs
+            // the geometric part (W_64^p)^r of the twiddle W_1024^(p (c + 16 r)): the pairs of
+            // alpha^(16/L) W_L^p', alpha = W_64^p, = W_(64 L)^(16 p + 64 p'), in fft_last<16>'s order.
+            // The inner twiddles W_256^(c q) carry the lane constant W_1024^(p c) and the exact 1/128.
+            std::vector<double2> ha((size_t)4 * 8), hb((size_t)64 * 16);
+            for (int pq = 0; pq < 4; ++pq) {
+                int k = 0;
+                for (int L = 2; L <= 16; L *= 2)
+                    for (int pp = 0; pp < (L >= 4 ? L / 4 : 1); ++pp) {
+                        long double c, sn;
+                        wn((long)pq * 16 + (long)pp * 64, (long)64 * L, &c, &sn);
+                        if (c == 0.0L) c = 1e-20L;
+                        ha[(size_t)pq * 8 + k++] = make_double2((double)c, (double)(sn / c));
+                    }
+            }
+            for (int t = 0; t < 64; ++t) {
+                const int pq = t >> 4, cc = t & 15;
+                for (int s = 0; s < 16; ++s) {
+                    long double c, sn;
+                    wn((long)cc * (4 * rev16h(s) + pq), 1024, &c, &sn);
+                    hb[(size_t)t * 16 + s] = make_double2((double)(c * 0.0078125L), (double)(sn * 0.0078125L));
+                }
+            }
+            if (!upload_table(ha, &tb.twxa_64) || !upload_table(hb, &tb.twxb_64)) {
+                free_tables(tb);
+                return -3;
+            }
+        }
     }
     e->tables[kF64Key + n_fft] = tb;
     *out = tb;
@@ -358,6 +392,7 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.blocks_per_cu = env_int("RTLWS_BLOCKS_PER_CU", 0);
     e->opt.f64_fused = env_int("RTLWS_F64_FUSED", 1);
     e->opt.f64_blocks_per_cu = env_int("RTLWS_F64_BLOCKS_PER_CU", 0);
+    e->opt.f64_x1024 = env_int("RTLWS_F64_X1024", 1);
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -391,6 +426,7 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "blocks_per_cu") e->opt.blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
+    else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
     else {
@@ -408,6 +444,7 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
     if (k == "blocks_per_cu") return e->opt.blocks_per_cu;
     if (k == "f64_fused") return e->opt.f64_fused;
     if (k == "f64_blocks_per_cu") return e->opt.f64_blocks_per_cu;
+    if (k == "f64_x1024") return e->opt.f64_x1024;
     if (k == "cic_direct") return e->opt.cic_direct;
     if (k == "cic_round") return e->opt.cic_round;
     if (k == "cu_count") return e->cu_count;
@@ -764,6 +801,8 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     p.tw2f = tb.tw2_64;
     p.hann_csf = tb.hann_cs64;
     p.rows_f32 = (d->flags & RTLWS_FLAG_ROWS_F32) && d->output != RTLWS_OUT_PAYLOAD_U8;
+    p.twxa = tb.twxa_64;
+    p.twxb = tb.twxb_64;
 
     int in_kind = d->input;
     if (d->cic_r > 1) in_kind = cic_in_kind(e, d->cic_r);
@@ -782,7 +821,12 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
         if (e->opt.f64_blocks_per_cu > 0 && e->opt.f64_blocks_per_cu <= 2 * per_cu) per_cu = e->opt.f64_blocks_per_cu;   // experiments only
         long blocks = (long)e->cu_count * per_cu;
         if (blocks > p.ngroups) blocks = p.ngroups;
-        switch (d->n_fft) {
+        // rectangular 1024-point cmplx_u8 frames: one LDS transposition instead of two
+        // (its dB / payload epilogues beside K-frame accumulators would spill: those stay where they were)
+        if (d->n_fft == 1024 && in_kind == rtlws::IN_CU8 && !p.window && e->opt.f64_x1024 && p.twxa &&
+            (d->output == RTLWS_OUT_POWER_SUM || d->k_avg == 1))
+            err = rtlws::launch_spectra_f64_1024x(p, (int)blocks, st);
+        else switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_f64_fused_1024(p, in_kind, (int)blocks, st, e->device); break;
         case 2048: err = rtlws::launch_spectra_f64_fused_2048(p, in_kind, (int)blocks, st, e->device); break;
         default: err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, (int)blocks, st, e->device); break;

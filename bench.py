@@ -404,13 +404,22 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # one sleeping wavefront on a queue of its own reads the shader-clock and 100 MHz counters when the
+    # timed region starts and when it ends: the clock THESE launches ran at (include/rtlws_hip.h,
+    # rtlws_clock_probe_*).  Started before t0; told to leave once the launches have drained, which the
+    # closing device synchronise then waits for (one poll, ~0.5 us).
+    probe = eng.clock_probe_start() if ctx.get("clock_probe", True) else None
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
     for i in range(steps):
         step(i)
     L.rtlws_event_record(ev1, eng.h, stream)
+    if probe is not None:
+        tstream.synchronize()
+        eng.clock_probe_signal(probe)
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0        # this rank's launches, before waiting for the others
+    sclk_ghz, probe_s = eng.clock_probe_stop(probe) if probe is not None else (None, None)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -475,11 +484,13 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": 1e6 * avg_launch_s},
         }
-        # (valu_issue_frac needs the shader clock of THESE launches; a clock measured on another
-        # launch series -- profiles/valu_insts.json -- is not this run's, so the field is only
-        # emitted when the caller supplies this run's own clock: tools/inkernel_clock.py)
-        if ctx.get("sclk_ghz_this_run"):
-            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), ctx["sclk_ghz_this_run"])
+        # valu_issue_frac needs the shader clock of THESE launches (a clock measured on another launch
+        # series is not this run's): the probe wavefront above measured it
+        if sclk_ghz:
+            result["roofline"]["sclk_ghz"] = sclk_ghz
+            result["roofline"]["sclk_source"] = ("d(s_memtime) / d(s_memrealtime) x 100 MHz of a probe wavefront resident "
+                                                 "beside the timed launches (%.1f ms, this run)" % (1e3 * probe_s))
+            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz)
             if vf is not None:
                 result["roofline"].update(vf)
         if world > 1:
@@ -741,6 +752,9 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads on the default line")
     ap.add_argument("--frames", type=int, default=0, help="override frames per step (experiments)")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="no probe wavefront beside the timed launches (rocprofv3 --pmc serialises kernels: the "
+                         "launches would wait for the probe)")
     ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
@@ -770,7 +784,7 @@ def main(argv=None):
     ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
            "rank": rank, "device": device,
            # ONE side stream carries input synthesis and every launch (run_workload, "Stream order")
-           "input": args.input,
+           "input": args.input, "clock_probe": not args.no_clock_probe,
            "stream": torch.cuda.Stream(device=device),
            "cu_count": torch.cuda.get_device_properties(device).multi_processor_count}
 

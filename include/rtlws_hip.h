@@ -270,6 +270,18 @@ int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, 
 int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float* d_prev_in,
                    float* d_prev_out, float* d_out, void* stream);
 
+/* ---- measurement: the shader clock DURING a timed region -------------------------------
+ * rtlws_clock_probe_start puts ONE wavefront on a queue of its own beside whatever the caller
+ * enqueues next; it records s_memtime (shader clocks) and s_memrealtime (100 MHz) when it starts and
+ * again when told to leave (rtlws_clock_probe_signal: returns at once; rtlws_clock_probe_stop:
+ * signals if that has not been done, then waits for the wavefront) or after ~10 s by itself, sleeping
+ * in between.  *sclk_ghz = d(memtime) / d(memrealtime) x 100 MHz: the clock the package power governor
+ * actually gave the kernels that ran in that interval (bench.py's roofline.valu_issue_frac uses
+ * it); *seconds = the interval.  start: NULL on failure; stop: 0 / -1 / -3 (the handle is consumed). */
+void* rtlws_clock_probe_start(rtlws_engine* e);
+void rtlws_clock_probe_signal(void* probe);
+int rtlws_clock_probe_stop(void* probe, double* sclk_ghz, double* seconds);
+
 /* Device-to-device copy on `stream` (delay-line upkeep of chained kernels). */
 int rtlws_copy_d2d(rtlws_engine* e, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 

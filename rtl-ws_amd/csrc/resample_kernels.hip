@@ -225,4 +225,34 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
     return hipGetLastError();
 }
 
+// ---- shader-clock probe (measurement infrastructure; include/rtlws_hip.h, rtlws_clock_probe_*) ----
+// ONE wavefront that sits beside the kernels being timed and reads the two hardware counters at its
+// start and when told to stop: s_memtime counts shader clocks, s_memrealtime a fixed 100 MHz
+// (MI355X_MICROARCH.md, DVFS): d(memtime) / d(memrealtime) x 100 MHz is the clock the chip actually
+// ran at over that interval -- the interval of the timed launches, not of another launch series.
+// It sleeps between polls (s_sleep: no issue slots, no memory traffic but one 4-byte read per ~0.5 us)
+// and ALWAYS terminates: on the stop flag, or after max_polls polls.
+__global__ __launch_bounds__(64) void clock_probe_kernel(const volatile int* stop, unsigned long long* out,
+                                                         int max_polls)
+{
+    const unsigned long long c0 = clock64(), r0 = wall_clock64();
+    int polls = 0;
+    while (polls < max_polls) {
+        __builtin_amdgcn_s_sleep(16);       // ~0.5 us between polls
+        ++polls;
+        if (*stop) break;
+    }
+    if (threadIdx.x == 0) {
+        out[0] = clock64() - c0;
+        out[1] = wall_clock64() - r0;
+        out[2] = (unsigned long long)polls;
+    }
+}
+
+hipError_t launch_clock_probe(const int* stop_flag, unsigned long long* out, int max_polls, hipStream_t st)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, stop_flag, out, max_polls);
+    return hipGetLastError();
+}
+
 }  // namespace rtlws

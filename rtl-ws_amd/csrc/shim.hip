@@ -934,6 +934,70 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq, long len, const float* d_p
     return 0;
 }
 
+// ---- shader-clock probe -------------------------------------------------------------------
+struct rtlws_clock_probe {
+    rtlws_engine* e = nullptr;
+    hipStream_t q = nullptr;            // its own queue: runs beside whatever the caller times
+    int* stop = nullptr;                // pinned, device-visible
+    unsigned long long* out = nullptr;  // pinned: {shader clocks, 100 MHz ticks, polls}
+};
+
+void* rtlws_clock_probe_start(rtlws_engine* e)
+{
+    g_err.clear();
+    NEED_ENGINE(e, nullptr);
+    HIP_TRY(hipSetDevice(e->device), nullptr);
+    rtlws_clock_probe* p = new rtlws_clock_probe;
+    p->e = e;
+    hipError_t err = hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->stop), sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->out), 3 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped);
+    if (err == hipSuccess) {
+        *p->stop = 0;
+        p->out[0] = p->out[1] = p->out[2] = 0;
+        // at most 2^24 polls of ~0.5 us: the wavefront leaves after ~10 s whatever the host does
+        err = rtlws::launch_clock_probe(p->stop, p->out, 1 << 24, p->q);
+    }
+    if (err != hipSuccess) {
+        set_err("rtlws_clock_probe_start", err);
+        if (p->q) (void)hipStreamDestroy(p->q);
+        if (p->stop) (void)hipHostFree(p->stop);
+        if (p->out) (void)hipHostFree(p->out);
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+void rtlws_clock_probe_signal(void* probe)
+{
+    rtlws_clock_probe* p = reinterpret_cast<rtlws_clock_probe*>(probe);
+    if (p) __atomic_store_n(p->stop, 1, __ATOMIC_RELEASE);
+}
+
+int rtlws_clock_probe_stop(void* probe, double* sclk_ghz, double* seconds)
+{
+    g_err.clear();
+    rtlws_clock_probe* p = reinterpret_cast<rtlws_clock_probe*>(probe);
+    if (!p) { g_err = "rtlws_clock_probe_stop: null probe"; return -1; }
+    int rc = 0;
+    (void)hipSetDevice(p->e->device);
+    __atomic_store_n(p->stop, 1, __ATOMIC_RELEASE);
+    hipError_t err = hipStreamSynchronize(p->q);
+    if (err != hipSuccess) { set_err("rtlws_clock_probe_stop", err); rc = -3; }
+    const double clocks = (double)p->out[0], ticks = (double)p->out[1];
+    if (rc == 0 && ticks <= 0.0) { g_err = "rtlws_clock_probe_stop: the probe recorded no interval"; rc = -3; }
+    if (rc == 0) {
+        if (sclk_ghz) *sclk_ghz = clocks / ticks * 0.1;       // ticks are 10 ns
+        if (seconds) *seconds = ticks * 1e-8;
+    }
+    (void)hipStreamDestroy(p->q);
+    (void)hipHostFree(p->stop);
+    (void)hipHostFree(p->out);
+    delete p;
+    return rc;
+}
+
 int rtlws_copy_d2d(rtlws_engine* e, void* dst, const void* src, size_t bytes, void* stream)
 {
     NEED_ENGINE(e, -1);

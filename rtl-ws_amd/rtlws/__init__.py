@@ -69,6 +69,7 @@ HIP_SYMBOLS = [
     "rtlws_fm_demod", "rtlws_copy_d2d", "rtlws_spectra_batch_f64", "rtlws_payload_from_sums_f64",
     "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64",
     "rtlws_queue_create", "rtlws_queue_destroy", "rtlws_queue_wait_event", "rtlws_event_create_blocking",
+    "rtlws_clock_probe_start", "rtlws_clock_probe_signal", "rtlws_clock_probe_stop",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
@@ -165,6 +166,11 @@ def hip_lib():
         L.rtlws_payload_from_sums.argtypes = [vp, vp, i, i, i, vp, vp]
         L.rtlws_fm_demod.argtypes = [vp, vp, l, vp, vp, vp, vp]
         L.rtlws_copy_d2d.argtypes = [vp, vp, vp, sz, vp]
+        L.rtlws_clock_probe_start.argtypes = [vp]
+        L.rtlws_clock_probe_start.restype = vp
+        L.rtlws_clock_probe_signal.argtypes = [vp]
+        L.rtlws_clock_probe_signal.restype = None
+        L.rtlws_clock_probe_stop.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rtlws_spectra_grid.argtypes = [vp, C.POINTER(SpectraDesc), l, C.POINTER(i),
                                          C.POINTER(i), C.POINTER(i)]
         _hip = L
@@ -317,6 +323,22 @@ class Engine:
 
     def sync(self, stream=None):
         self._chk(hip_lib().rtlws_stream_sync(self.h, stream), "sync")
+
+    def clock_probe_start(self):
+        """A wavefront beside the next launches that measures the shader clock they run at."""
+        h = hip_lib().rtlws_clock_probe_start(self.h)
+        if not h:
+            raise RuntimeError("rtlws_clock_probe_start failed: %s" % last_error())
+        return h
+
+    def clock_probe_signal(self, probe):
+        hip_lib().rtlws_clock_probe_signal(probe)
+
+    def clock_probe_stop(self, probe):
+        """(sclk_ghz, seconds) of the interval since clock_probe_start."""
+        g, s = C.c_double(0.0), C.c_double(0.0)
+        self._chk(hip_lib().rtlws_clock_probe_stop(probe, C.byref(g), C.byref(s)), "rtlws_clock_probe_stop")
+        return g.value, s.value
 
     def set_option(self, name, value):
         """Kernel-selection switch of this engine (include/rtlws_hip.h: rtlws_engine_set_option)."""

@@ -54,7 +54,10 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
         assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
         assert r["dtype"] == ("int32" if name == "cic8_block_sums" else
                               {"f32": "f32", "f64": "f64", "f64c_f32o": "f64 arithmetic, f32 rows"}[prec])
-        assert "valu_issue_frac" not in roof                  # no shader clock of THIS run: no such field
+        # the shader clock of THIS run's timed launches, measured beside them (rtlws_clock_probe_*)
+        assert 0.5 < roof["sclk_ghz"] < 2.6 and "this run" in roof["sclk_source"]
+        if "valu_issue_frac" in roof:                         # (only workloads with a committed instruction count)
+            assert "own shader clock" in roof["valu_issue_source"] and 0.05 < roof["valu_issue_frac"] < 1.0
         n_fft, k_avg, _, output, cic_r, _ = bench.WORKLOADS[name]
         if output in ("power_sum", "mean_db"):               # rows priced at what was stored
             per_frame = 2 * n_fft * max(cic_r, 1) + (8 if prec == "f64" else 4) * n_fft // k_avg
@@ -130,3 +133,25 @@ def test_two_ranks_rehearsal_on_one_gpu():
     assert len(pr["ms_per_step_own"]["all"]) == 2 and len(pr["event_ms_per_step"]["all"]) == 2
     assert pr["ms_per_step_own"]["max"] <= r["ms_per_step"] * 1.001
     assert "failed" not in r["parity"] and r["scaling"] == "weak"
+
+
+def test_clock_probe_measures_a_plausible_clock_and_always_leaves(ctx):
+    """rtlws_clock_probe_*: the probe wavefront beside a series of launches reports a shader clock in
+    the chip's range and the length of the interval; stopping it at once (nothing launched) works too."""
+    import time
+    eng, rtlws = ctx["eng"], ctx["rtlws"]
+    from rtlws import synth
+    iq = eng.upload(synth.tone_noise_iq(4096, 1024, seed=3))
+    out = eng.alloc(4096 * 1024 * 4)
+    desc = rtlws.make_desc(1024)
+    probe = eng.clock_probe_start()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        eng.spectra_batch(desc, iq, 4096, out)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    ghz, secs = eng.clock_probe_stop(probe)
+    assert 0.5 < ghz < 2.6, ghz
+    assert 0.5 * dt < secs < dt + 0.05
+    ghz2, secs2 = eng.clock_probe_stop(eng.clock_probe_start())
+    assert 0.3 < ghz2 < 2.6 and secs2 < 0.05

@@ -30,6 +30,19 @@ for N in (1024, 4096):
     ps = np.zeros(N)
     print("spectrum_add_cmplx_u8  N=%-5d %8.1f us/call" % (N, timeit(lambda: s.add_cmplx_u8(frame, ps), 2000)))
     s.free()
+# the decimator's output fed to a spectrum (SURVEY.md §8a row a3 / configs[3]'s composition through the
+# reference API: rf_decimator -> spectrum_add_cmplx_s32, src/spectrum.c:65-81) and the real-f32 entry
+# point: one launch of the fused f64 kernel on the cmplx_s32 / f32 input kinds (round 4), or of the
+# row-per-workgroup kernel with RTLWS_F64_FUSED=0
+rng = np.random.default_rng(5)
+for N in (1024, 2048, 4096):
+    s = rtlws.Spectrum(N)
+    s32 = rng.integers(-1024, 1024, size=(N, 2), dtype=np.int32)
+    f32 = rng.standard_normal(N).astype(np.float32)
+    ps = np.zeros(N)
+    print("spectrum_add_cmplx_s32 N=%-5d %8.1f us/call" % (N, timeit(lambda: s.add_cmplx_s32(s32, ps), 2000)))
+    print("spectrum_add_real_f32  N=%-5d %8.1f us/call" % (N, timeit(lambda: s.add_real_f32(f32, ps), 2000)))
+    s.free()
 blk = synth.uniform_iq(1, 204800, seed=3).reshape(-1, 2)       # 100 ms at 2.048 MS/s
 print("cic_decimate R=10, 204800 samples   %8.1f us/call" % timeit(lambda: rtlws.cic_decimate(10, blk), 200))
 blk8 = synth.uniform_iq(1, 153600, seed=3).reshape(-1, 2)

@@ -22,7 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def pmc(workload):
-    return json.load(open(os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)))["counters"]
+    """the newest committed counter file of the workload (the kernel a line is priced with)"""
+    for tag in ("r04", "r03"):
+        f = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (tag, workload))
+        if os.path.exists(f):
+            return json.load(open(f))["counters"]
+    raise FileNotFoundError(workload)
 
 
 def entry(workload, frames, four_cycle_per_frame, sclk_ghz, note):
@@ -47,11 +52,16 @@ def main():
                                            "spectra_fused<1024, u8, rect, sum, K=1>: 32 byte conversions per frame at 4 "
                                            "cycles; in-kernel clock 2.007 GHz median (p10-p90 1.936-2.078; another box's "
                                            "rocm-smi: 1.884-1.892 GHz at 1 394-1 402 W, the cap)"),
-        # per frame (one wavefront): 386 f64 arithmetic + 32 conversions to f64 + 32 SDWA integer adds at 4 cycles
-        "batched_1024pt_64k_frames_f64": entry("batched_1024pt_64k_frames_f64", 65536, 386 + 32 + 32, 2.03,
-                                               "spectra_f64_fused<rect, sum, K=1>: 386 f64 add / mul / fma, 32 "
-                                               "v_cvt_f64_*, 32 SDWA integer adds per frame at 4 cycles; rocm-smi sclk "
-                                               "2.02-2.05 GHz at 1 375-1 382 W (no stamped build of this kernel)"),
+        # round 4, spectrum_f64_1024x.hip (one wavefront per frame): 436 f64 add / mul / fma + 32 v_cvt_f64_i32 at 4
+        # cycles (+ 16 v_cvt_f32_f64 with f32 rows); the ~115 integer / cross-lane / address instructions at 2
+        "batched_1024pt_64k_frames_f64": entry("batched_1024pt_64k_frames_f64", 65536, 436 + 32, 2.03,
+                                               "spectra_f64_1024x<sum, K=1, f64 rows>: 436 f64 add / mul / fma + 32 "
+                                               "v_cvt_f64_i32 per frame at 4 cycles; rocm-smi sclk 2.02-2.05 GHz at "
+                                               "1 375-1 382 W (bench.py measures its own run's clock: roofline.sclk_ghz)"),
+        "batched_1024pt_64k_frames_f64c_f32o": entry("batched_1024pt_64k_frames_f64c_f32o", 65536, 436 + 32 + 16, 2.01,
+                                                     "spectra_f64_1024x<sum, K=1, f32 rows>: 436 f64 add / mul / fma + 32 "
+                                                     "v_cvt_f64_i32 + 16 v_cvt_f32_f64 per frame at 4 cycles; rocm-smi "
+                                                     "sclk 2.00-2.02 GHz at 1 380-1 386 W (profiles/r04_power_clocks.txt)"),
     }
     json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
     for k, v in out.items():

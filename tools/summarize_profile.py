@@ -54,7 +54,7 @@ def main():
     dominant = None
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        ours = [r for r in rows if "rtlws::" in r["Name"]]
+        ours = [r for r in rows if "rtlws::" in r["Name"] and "clock_probe_kernel" not in r["Name"]]
         ours.sort(key=lambda r: -float(r["TotalDurationNs"]))
         with open(dst + "_kernel_stats.csv", "w") as f:
             f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,StdDev\n")

@@ -411,18 +411,29 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     probe = eng.clock_probe_start() if ctx.get("clock_probe", True) else None
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
+    tA = time.perf_counter()
     for i in range(steps):
         step(i)
+    tB = time.perf_counter()
     L.rtlws_event_record(ev1, eng.h, stream)
+    tC = time.perf_counter()
     if probe is not None:
         tstream.synchronize()
+        tD = time.perf_counter()
         eng.clock_probe_signal(probe)
+    else:
+        tD = tC
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0        # this rank's launches, before waiting for the others
-    sclk_ghz, probe_s = eng.clock_probe_stop(probe) if probe is not None else (None, None)
+    if os.environ.get("RTLWS_BENCH_DEBUG"):
+        print("DEBUG %s probe=%s: ev0 %.3f ms, enqueue %.3f, ev1 %.3f, stream sync %.3f, device sync %.3f, total %.3f" % (
+            name, probe is not None, 1e3 * (tA - t0), 1e3 * (tB - tA), 1e3 * (tC - tB), 1e3 * (tD - tC),
+            1e3 * (t0 + own_elapsed - tD), 1e3 * own_elapsed), file=sys.stderr)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # (after the clock has stopped: releasing the probe's queue and pinned words takes ~1 ms)
+    sclk_ghz, probe_s = eng.clock_probe_stop(probe) if probe is not None else (None, None)
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
@@ -490,7 +501,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             result["roofline"]["sclk_ghz"] = sclk_ghz
             result["roofline"]["sclk_source"] = ("d(s_memtime) / d(s_memrealtime) x 100 MHz of a probe wavefront resident "
                                                  "beside the timed launches (%.1f ms, this run)" % (1e3 * probe_s))
-            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz)
+            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
             if vf is not None:
                 result["roofline"].update(vf)
         if world > 1:
@@ -524,9 +535,10 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
 # conversions, SDWA and every f64 instruction; tools/make_valu_insts.py, profiles/valu_insts.json) /
 # the SIMD-cycles this run's launch lasted (4 SIMDs per CU x CUs x launch time x the shader clock
 # rocm-smi showed under sustained load of the same workload, committed beside the count).
-def valu_issue_frac(name, avg_launch_s, cu_count, sclk_ghz=None):
+def valu_issue_frac(name, avg_launch_s, cu_count, sclk_ghz=None, frames=None):
     """sclk_ghz: the shader clock of the launches `avg_launch_s` was measured on (None: the
-    committed clock of another launch series -- only for offline use, never in the bench line)."""
+    committed clock of another launch series -- only for offline use, never in the bench line).
+    frames: frames per launch of this run (None: the committed count's own)."""
     path = os.path.join(ROOT, "profiles", "valu_insts.json")
     try:
         rec = json.load(open(path)).get(name)
@@ -536,7 +548,8 @@ def valu_issue_frac(name, avg_launch_s, cu_count, sclk_ghz=None):
         return None
     own = sclk_ghz is not None
     simd_cycles = 4 * cu_count * avg_launch_s * (sclk_ghz if own else rec["sclk_ghz_under_load"]) * 1e9
-    return {"valu_issue_frac": rec["issue_cycles_per_launch"] / simd_cycles,
+    issue = rec["issue_cycles_per_launch"] * (1.0 if frames is None else frames / rec["frames_per_launch"])
+    return {"valu_issue_frac": issue / simd_cycles,
             "valu_issue_source": ("profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost: committed count) / "
                                   "this run's launch duration at this run's own shader clock (%.3f GHz)" % sclk_ghz) if own else
                                  "profiles/valu_insts.json (SQ_INSTS_VALU per launch by issue cost, sclk under "

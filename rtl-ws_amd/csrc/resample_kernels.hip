@@ -232,15 +232,18 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
 // ran at over that interval -- the interval of the timed launches, not of another launch series.
 // It sleeps between polls (s_sleep: no issue slots, no memory traffic but one 4-byte read per ~0.5 us)
 // and ALWAYS terminates: on the stop flag, or after max_polls polls.
-__global__ __launch_bounds__(64) void clock_probe_kernel(const volatile int* stop, unsigned long long* out,
+__global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsigned long long* out,
                                                          int max_polls)
 {
     const unsigned long long c0 = clock64(), r0 = wall_clock64();
+    if (threadIdx.x == 0) {                 // tells the host it is resident: the caller's clock starts after this
+        __hip_atomic_store(&out[3], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     int polls = 0;
     while (polls < max_polls) {
         __builtin_amdgcn_s_sleep(16);       // ~0.5 us between polls
         ++polls;
-        if (*stop) break;
+        if (__hip_atomic_load(stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) break;   // past every cache
     }
     if (threadIdx.x == 0) {
         out[0] = clock64() - c0;

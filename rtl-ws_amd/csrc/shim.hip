@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <string>
@@ -939,7 +940,7 @@ struct rtlws_clock_probe {
     rtlws_engine* e = nullptr;
     hipStream_t q = nullptr;            // its own queue: runs beside whatever the caller times
     int* stop = nullptr;                // pinned, device-visible
-    unsigned long long* out = nullptr;  // pinned: {shader clocks, 100 MHz ticks, polls}
+    unsigned long long* out = nullptr;  // pinned: {shader clocks, 100 MHz ticks, polls, resident flag}
 };
 
 void* rtlws_clock_probe_start(rtlws_engine* e)
@@ -950,13 +951,21 @@ void* rtlws_clock_probe_start(rtlws_engine* e)
     rtlws_clock_probe* p = new rtlws_clock_probe;
     p->e = e;
     hipError_t err = hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->stop), sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
-    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->out), 3 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->stop), sizeof(int), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void**>(&p->out), 4 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
     if (err == hipSuccess) {
         *p->stop = 0;
-        p->out[0] = p->out[1] = p->out[2] = 0;
+        p->out[0] = p->out[1] = p->out[2] = p->out[3] = 0;
         // at most 2^24 polls of ~0.5 us: the wavefront leaves after ~10 s whatever the host does
         err = rtlws::launch_clock_probe(p->stop, p->out, 1 << 24, p->q);
+        // The first launch on a new queue sets the queue up (about a millisecond, during which launches
+        // on other queues wait): return only once the wavefront is resident, so none of that lands in
+        // the interval the caller is about to time.  Bounded: ~2 s, then the probe is used as it is.
+        for (long spin = 0; err == hipSuccess && spin < 2000000L; ++spin) {
+            if (__atomic_load_n(&p->out[3], __ATOMIC_ACQUIRE)) break;
+            struct timespec ts = {0, 1000};
+            nanosleep(&ts, nullptr);
+        }
     }
     if (err != hipSuccess) {
         set_err("rtlws_clock_probe_start", err);

@@ -147,7 +147,7 @@ def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
     import bench
     (tmp_path / "profiles").mkdir()
     (tmp_path / "profiles" / "valu_insts.json").write_text(json.dumps(
-        {"w": {"issue_cycles_per_launch": 8.0e7, "sclk_ghz_under_load": 2.0}}))
+        {"w": {"issue_cycles_per_launch": 8.0e7, "sclk_ghz_under_load": 2.0, "frames_per_launch": 65536}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     out = bench.valu_issue_frac("w", 80e-6, 256)
     # 8e7 issue cycles over 4 SIMDs x 256 CUs x 80 us x 2 GHz
@@ -155,6 +155,8 @@ def test_valu_issue_frac_arithmetic(tmp_path, monkeypatch):
     assert "ANOTHER launch series" in out["valu_issue_source"]
     own = bench.valu_issue_frac("w", 80e-6, 256, sclk_ghz=2.2)      # the run's own clock: what a line may carry
     assert abs(own["valu_issue_frac"] - 8.0e7 / (1024 * 80e-6 * 2.2e9)) < 1e-12 and "own shader clock" in own["valu_issue_source"]
+    half = bench.valu_issue_frac("w", 40e-6, 256, sclk_ghz=2.2, frames=32768)     # half the frames in half the time
+    assert abs(half["valu_issue_frac"] - own["valu_issue_frac"]) < 1e-12
     assert bench.valu_issue_frac("other", 80e-6, 256) is None
 
 

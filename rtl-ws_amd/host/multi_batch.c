@@ -93,7 +93,7 @@ rtlws_multi* rtlws_multi_open(int n_shards, const int* device_ids, const rtlws_s
         s->ev0 = rtlws_event_create();
         s->ev1 = rtlws_event_create();
         if (!s->d_in || !s->d_out || !s->ev0 || !s->ev1 ||
-            (m->f64 ? 0 : rtlws_engine_prepare(s->eng, desc->n_fft))) {
+            (m->f64 ? rtlws_engine_prepare_f64(s->eng, desc->n_fft) : rtlws_engine_prepare(s->eng, desc->n_fft))) {
             rtlws_multi_close(m);
             return NULL;
         }

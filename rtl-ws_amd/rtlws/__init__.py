@@ -60,7 +60,7 @@ class CicDelayLine(C.Structure):
 # every symbol include/*.h declares, by library (tests check the exports)
 HIP_SYMBOLS = [
     "rtlws_device_count", "rtlws_engine_create", "rtlws_engine_destroy", "rtlws_engine_device",
-    "rtlws_engine_prepare", "rtlws_engine_set_option", "rtlws_engine_get_option",
+    "rtlws_engine_prepare", "rtlws_engine_prepare_f64", "rtlws_engine_set_option", "rtlws_engine_get_option",
     "rtlws_last_error", "rtlws_dev_alloc", "rtlws_dev_free", "rtlws_pinned_alloc",
     "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
     "rtlws_stream_sync", "rtlws_event_create", "rtlws_event_destroy", "rtlws_event_record",
@@ -131,6 +131,7 @@ def hip_lib():
         L.rtlws_engine_destroy.argtypes = [vp]
         L.rtlws_engine_device.argtypes = [vp]
         L.rtlws_engine_prepare.argtypes = [vp, i]
+        L.rtlws_engine_prepare_f64.argtypes = [vp, i]
         L.rtlws_engine_set_option.argtypes = [vp, C.c_char_p, i]
         L.rtlws_engine_get_option.argtypes = [vp, C.c_char_p]
         L.rtlws_last_error.restype = C.c_char_p

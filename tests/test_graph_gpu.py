@@ -46,3 +46,37 @@ def test_capture_and_replay(built, oracle):
     torch.cuda.synchronize()
     assert torch.equal(eager, out[3])
     eng.close()
+
+
+def test_capture_and_replay_f64(built, oracle):
+    """The same for rtlws_spectra_batch_f64 once rtlws_engine_prepare_f64 has built its tables:
+    f64 rows, and f64 arithmetic with f32 rows, captured and replayed."""
+    import torch
+    from rtlws import synth
+    from helpers import EPS_STRICT
+    dev = torch.device("cuda", 0)
+    eng = built.Engine(0)
+    N, nframes, launches = 1024, 256, 4
+    assert built.hip_lib().rtlws_engine_prepare_f64(eng.h, N) == 0
+    assert built.hip_lib().rtlws_engine_prepare_f64(eng.h, 9000) == -1
+    iq_host = synth.tone_noise_iq(nframes * launches, N, seed=19).reshape(launches, nframes, N, 2)
+    iq = torch.from_numpy(iq_host).to(dev)
+    out64 = torch.zeros((launches, nframes, N), dtype=torch.float64, device=dev)
+    out32 = torch.zeros((launches, nframes, N), dtype=torch.float32, device=dev)
+    d64, d32 = built.make_desc(N), built.make_desc(N, flags=built.FLAG_ROWS_F32)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for i in range(launches):
+                eng.spectra_batch_f64(d64, iq[i].data_ptr(), nframes, out64[i].data_ptr(), stream=built.torch_stream_handle())
+                eng.spectra_batch_f64(d32, iq[i].data_ptr(), nframes, out32[i].data_ptr(), stream=built.torch_stream_handle())
+    torch.cuda.current_stream().wait_stream(side)
+    assert float(out64.abs().sum()) == 0.0
+    g.replay()
+    torch.cuda.synchronize()
+    ref = oracle.batch_spectra_u8(iq_host[2], N, nthreads=8)
+    assert rel_err(out64[2].cpu().numpy(), ref, EPS_STRICT).max() <= 1e-10
+    assert torch.equal(out32, out64.to(torch.float32))
+    eng.close()

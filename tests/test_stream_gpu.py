@@ -194,3 +194,30 @@ def test_stream_queue_per_slot_and_one_queue_give_the_same_rows(built, oracle, q
     want = np.stack([oracle.spectrum_payload(r, 2, 15) for r in ref])
     diff = np.abs(rows.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() < 5e-3       # f32 batch kernel: +-1 only next to an integer dB
+
+
+def test_stream_on_the_last_device(built, oracle):
+    """the zero-copy paths have kernels of the stream's device write pinned host memory
+    allocated on whatever thread opened the stream; exercised here on a device that is not 0."""
+    n = built.device_count()
+    if n < 2:
+        pytest.skip("one HIP device on this box")
+    from rtlws import synth
+    L = _lib(built)
+    N, frames_per_chunk = 1024, 64
+    iq = synth.tone_noise_iq(frames_per_chunk * 4, N, seed=77)
+    got = []
+
+    @CB
+    def cb(rows, nrows, first_frame, lat, user):
+        got.append(np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_float)), shape=(nrows, N)).copy())
+
+    desc = built.make_desc(N)
+    s = L.rtlws_stream_open(n - 1, C.byref(desc), frames_per_chunk, 3, cb, None)
+    assert s
+    for c in range(4):
+        chunk = np.ascontiguousarray(iq[c * frames_per_chunk:(c + 1) * frames_per_chunk])
+        assert L.rtlws_stream_push(s, chunk.ctypes.data_as(C.c_void_p), 1) == 0
+    L.rtlws_stream_flush(s)
+    L.rtlws_stream_close(s)
+    assert rel_err(np.concatenate(got), oracle.batch_spectra_u8(iq, N, nthreads=4), EPS_K1).max() <= TOL

@@ -39,7 +39,8 @@ while time.time() - t0 < budget_s:
     out = str(rng.choice(["power_sum", "power_sum", "mean_db", "payload_u8"]))
     gain = int(rng.choice([0, 15, -25, 40, -9, 9]))
     kind = str(rng.choice(["cu8", "cu8", "cu8", "cs32", "rf32"]))
-    cic_r = int(rng.choice([0, 0, 3, 8, 10, 12])) if (kind == "cu8" and N <= 2048) else 0
+    cic_r = int(rng.choice([0, 0, 3, 8, 10, 12])) if (kind == "cu8" and N <= (4096 if fused_size else 2048)) else 0
+    rows_f32 = bool(out != "payload_u8" and rng.random() < 0.3)      # RTLWS_FLAG_ROWS_F32: one f32 rounding
     w = None if window == "rect" else synth.hann(N)
     if kind == "cu8":
         gen = [synth.tone_noise_iq, synth.uniform_iq, synth.pure_tone_iq][int(rng.integers(0, 3))]
@@ -59,9 +60,21 @@ while time.time() - t0 < budget_s:
             for k in range(K):
                 assert add(N, data[r * K + k], ref[r], window=w) == 0
     got = eng.spectra(data, N, k_avg=K, input=kind, window=window, output=out, cic_r=cic_r,
-                      gain_db=gain, f64=True)
-    tag = "N=%d K=%d rows=%d win=%s cic=%d out=%s gain=%d %s" % (N, K, rows, window, cic_r, out, gain, kind)
-    if out == "power_sum":
+                      gain_db=gain, f64=True, rows_f32=rows_f32)
+    tag = "N=%d K=%d rows=%d win=%s cic=%d out=%s gain=%d %s%s" % (N, K, rows, window, cic_r, out, gain, kind,
+                                                                  " f32rows" if rows_f32 else "")
+    if rows_f32:
+        assert got.dtype == np.float32, tag
+        if out == "power_sum":
+            big = ref.max() < 3e38                                # (int32-extreme frames overflow an f32 row)
+            e = rel_err(got, ref, EPS_STRICT).max() if big else 0.0
+            assert e <= 6.0e-8, (tag, e)
+        else:
+            ok = ref > 1e-9 * ref.max(axis=1, keepdims=True)
+            with np.errstate(divide="ignore"):
+                want = 10 * np.log10(ref / K)
+            assert np.abs(got - want)[ok].max() <= 2e-5, (tag, float(np.abs(got - want)[ok].max()))
+    elif out == "power_sum":
         e = rel_err(got, ref, EPS_STRICT).max()
         worst = max(worst, e)
         assert e <= TOL_F64, (tag, e)

@@ -184,18 +184,12 @@ static void free_engine_side(void)
     g_eng = NULL;
 }
 
-void cbb_init(int decimated_bw_target_hz)
+/* the device side of cbb_init (replaces spectrum_alloc, reference src/cbb_main.c:83); 0 / -3 */
+static int init_engine_side(void)
 {
-    rtl_init(&g_dev, DEV_INDEX);                                  /* :77 */
-
-    g_decim = rf_decimator_alloc();                               /* :79-80 */
-    rf_decimator_set_parameters(g_decim, rtl_sample_rate(g_dev),
-                                (int)(rtl_sample_rate(g_dev) / (uint32_t)decimated_bw_target_hz));
-
-    g_eng = rtlws_engine_create(rtlws_host_device());             /* replaces spectrum_alloc, :83 */
-    if (!g_eng)                                 /* no CPU path to fall back to, and no reason to */
-        rtlws_host_fail("cbb_init", rtlws_last_error());      /* take the server down: inert spectrum side */
-    if (g_eng) {
+    int k;
+    g_eng = rtlws_engine_create(rtlws_host_device());
+    if (!g_eng) return -3;
     {   /* the reference transforms 6 of the ~128 frames a sensor
          * buffer carries (:46-49); with RTLWS_CBB_ALL_FRAMES=1 the same launch averages
          * all of them (K = len/1024) -- same payload format, smoother spectrum */
@@ -212,21 +206,30 @@ void cbb_init(int decimated_bw_target_hz)
     if (g_d_acc) rtlws_memset_dev(g_eng, g_d_acc, 0, FFT_POINTS * sizeof(double), NULL);
     if (g_d_b) rtlws_memset_dev(g_eng, g_d_b, 0, sizeof(double), NULL);
     g_acc_count = 0;
-    {
-        int k;
-        for (k = 0; k < IQ_SLOTS; ++k) {
-            g_h_iq[k] = (cmplx_u8*)rtlws_pinned_alloc((size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
-            g_iq_done[k] = rtlws_event_create();
-            g_iq_used[k] = 0;
-        }
-        g_iq_next = 0;
+    for (k = 0; k < IQ_SLOTS; ++k) {
+        g_h_iq[k] = (cmplx_u8*)rtlws_pinned_alloc((size_t)g_max_blocks * FFT_POINTS * sizeof(cmplx_u8));
+        g_iq_done[k] = rtlws_event_create();
+        g_iq_used[k] = 0;
     }
+    g_iq_next = 0;
     g_h_payload = (unsigned char*)rtlws_pinned_alloc(FFT_POINTS);
     if (!g_d_iq || !g_d_work || !g_d_pub || !g_d_payload || !g_d_acc || !g_d_b || !g_h_iq[0] || !g_h_iq[1] ||
-        !g_iq_done[0] || !g_iq_done[1] || !g_h_payload) {
-        rtlws_host_fail("cbb_init", rtlws_last_error());
-        free_engine_side();                     /* inert, as without a device */
-    }
+        !g_iq_done[0] || !g_iq_done[1] || !g_h_payload)
+        return -3;
+    return 0;
+}
+
+void cbb_init(int decimated_bw_target_hz)
+{
+    rtl_init(&g_dev, DEV_INDEX);                                  /* :77 */
+
+    g_decim = rf_decimator_alloc();                               /* :79-80 */
+    rf_decimator_set_parameters(g_decim, rtl_sample_rate(g_dev),
+                                (int)(rtl_sample_rate(g_dev) / (uint32_t)decimated_bw_target_hz));
+
+    if (init_engine_side() != 0) {              /* no CPU path to fall back to, and no reason to take the */
+        rtlws_host_fail("cbb_init", rtlws_last_error());      /* server down: inert spectrum side (rtlws_host.h) */
+        free_engine_side();
     }
     g_pub_count = 0;
     g_last_est_ms = 0;

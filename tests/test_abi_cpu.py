@@ -286,3 +286,24 @@ def test_f64_fused_lds_layout_is_conflict_free():
     for N in (2048, 4096):
         per_wave = lds_sim.analyse_f64_n(N, verbose=False)
         assert all(w == (128, 64, 128, 64) for w in per_wave), (N, per_wave)
+
+
+def test_cbb_init_without_a_gpu_leaves_the_server_alive(built):
+    """cbb_init returns void (src/cbb_main.c:72).  Without a device it used to abort() the process
+    it was linked into; now the spectrum side is inert -- the sensor keeps being drained, no spectrum
+    is ever announced, the payload call returns 0 bytes -- and the failure is on record.  Run in a
+    child process (the synthetic sensor owns a thread)."""
+    import subprocess
+    if built.device_count() > 0:
+        pytest.skip("a GPU is present")
+    code = (
+        "import sys, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import rtlws\n"
+        "L = rtlws.cbb_lib(); rtlws.host_error_clear(); L.cbb_init(192000); time.sleep(0.4)\n"
+        "n, msg = rtlws.host_error()\n"
+        "assert L.cbb_new_spectrum_available() == 0 and len(rtlws.cbb_payload(0)) == 0\n"
+        "assert L.rtlws_cbb_samples_seen() > 0 and n == 1 and msg.startswith('cbb_init: '), (n, msg)\n"
+        "L.cbb_close(); print('alive')\n" % (ROOT, os.path.join(ROOT, "rtl-ws_amd")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip().endswith("alive"), out.stderr[-2000:]

@@ -102,6 +102,7 @@ def test_config2_full_size_every_bin_of_every_row_against_the_fftw_api(fftw_api,
         iq[f, :, 1] = np.clip(np.round(77 * np.sin(ph) + 128 + rng.normal(0, 6, N)), 0, 255)
     got32 = engine.spectra(iq, N)
     got64 = engine.spectra(iq, N, f64=True)
+    got6432 = engine.spectra(iq, N, f64=True, rows_f32=True)     # f64 arithmetic, f32 rows (round 4)
 
     L = fftw_api
     L.fftw_execute_dft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -109,7 +110,7 @@ def test_config2_full_size_every_bin_of_every_row_against_the_fftw_api(fftw_api,
     y0 = np.zeros(N, dtype=np.complex128)
     plan = L.fftw_plan_dft_1d(N, x0.ctypes.data_as(C.c_void_p), y0.ctypes.data_as(C.c_void_p), FFTW_FORWARD, FFTW_ESTIMATE)
     assert plan
-    worst32 = worst64 = 0.0
+    worst32 = worst64 = worst6432 = 0.0
     chunk = 4096
     for a in range(0, nframes, chunk):
         x = ((iq[a:a + chunk].astype(np.float64) - 128.0) / 128.0).view(np.complex128).reshape(-1, N)
@@ -123,9 +124,11 @@ def test_config2_full_size_every_bin_of_every_row_against_the_fftw_api(fftw_api,
         mx = ref.max(axis=1, keepdims=True)
         worst64 = max(worst64, float((np.abs(got64[a:a + chunk] - ref) / np.maximum(ref, 1e-9 * mx)).max()))
         worst32 = max(worst32, float((np.abs(got32[a:a + chunk].astype(np.float64) - ref) / np.maximum(ref, 1e-5 * mx)).max()))
+        worst6432 = max(worst6432, float((np.abs(got6432[a:a + chunk].astype(np.float64) - ref) / np.maximum(ref, 1e-9 * mx)).max()))
     L.fftw_destroy_plan(plan)
     assert worst64 <= 1e-10, worst64
     assert worst32 <= 1e-4, worst32
+    assert worst6432 <= 6.0e-8, worst6432          # strict floor, one f32 rounding: north_star's 1e-4 with no floor of ours
 
 
 def _fftw_rows(L, x):
@@ -175,12 +178,13 @@ def test_config4_full_size_against_the_fftw_api(fftw_api, engine):
     """configs[3] at full size (8 192 spectra of 2048 points from 16 384 raw IQ samples each, CIC
     8:1 fused): the block sums of (x - 128) in numpy integers (src/resample.c:24-25,35), /128
     (src/spectrum.c:74-75), the transform through the FFTW3 API; every bin of every row within the
-    f32 budget."""
+    f32 budget, and within the strict 1e-10 for the fused f64 kernel."""
     from rtlws import synth
     nspec, N, R = 8192, 2048, 8
     iq = synth.tone_noise_iq(nspec, N * R, seed=505)
     got = engine.spectra(iq, N, cic_r=R).astype(np.float64)
-    worst = 0.0
+    got64 = engine.spectra(iq, N, cic_r=R, f64=True)            # the reference's precision, one launch (round 4)
+    worst = worst64 = 0.0
     chunk = 1024
     for a in range(0, nspec, chunk):
         s = (iq[a:a + chunk].astype(np.int32) - 128).reshape(-1, N, R, 2).sum(axis=2)
@@ -191,4 +195,6 @@ def test_config4_full_size_against_the_fftw_api(fftw_api, engine):
         ref[:, N // 2] = ref[:, N // 2 - 1]
         mx = ref.max(axis=1, keepdims=True)
         worst = max(worst, float((np.abs(got[a:a + chunk] - ref) / np.maximum(ref, 1e-5 * mx)).max()))
+        worst64 = max(worst64, float((np.abs(got64[a:a + chunk] - ref) / np.maximum(ref, 1e-9 * mx)).max()))
     assert worst <= 1e-4, worst
+    assert worst64 <= 1e-10, worst64

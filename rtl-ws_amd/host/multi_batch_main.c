@@ -5,8 +5,12 @@
  *
  *   rtlws_multi_batch [--frames B] [--nfft N] [--k K] [--launches L] [--warmup W] [--devices D]
  *                     [--precision f32|f64|f64c_f32o] [--window hann] [--output f32|db|payload]
- *                     [--cic R] [--shards-on-device0 S] [--plan-only]
+ *                     [--cic R] [--shards-per-device Q] [--shards-on-device0 S] [--plan-only]
  *   --devices D            use the first D devices (default: all)
+ *   --shards-per-device Q  cut every device's share into Q shards with their own engine, queue and host
+ *                          thread (device order 0,0,..,1,1,..): consecutive launches of different queues
+ *                          overlap each other's fill and drain phases -- one MI355X: 0.66 of the HBM
+ *                          roofline with Q = 1, 0.71-0.72 with Q = 2 or 3 (profiles/r04_shards_one_device.txt)
  *   --shards-on-device0 S  rehearsal: S shards, all on device 0 (the S-shard code path on one GPU;
  *                          the line says so and is not a scaling measurement)
  *   --plan-only            print the frame ranges for --devices D and exit: no GPU is touched
@@ -37,7 +41,7 @@ static void synth_iq(unsigned char* buf, long samples)
 int main(int argc, char** argv)
 {
     long frames = 65536;
-    int nfft = 1024, k = 1, launches = 200, warmup = 500, devices = 0, plan_only = 0, rehearsal = 0, cic = 0, i, g, n;
+    int nfft = 1024, k = 1, launches = 200, warmup = 500, devices = 0, plan_only = 0, rehearsal = 0, cic = 0, per_dev = 1, i, g, n;
     int output = RTLWS_OUT_POWER_SUM, window = RTLWS_WIN_RECT, flags = 0, f64 = 0, rc;
     const char* precision = "f32";
     const char* output_name = "f32";
@@ -56,6 +60,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--cic") && i + 1 < argc) cic = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--shards-on-device0") && i + 1 < argc) rehearsal = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--shards-per-device") && i + 1 < argc) per_dev = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--plan-only")) plan_only = 1;
         else if (!strcmp(argv[i], "--window") && i + 1 < argc) window = !strcmp(argv[++i], "hann") ? RTLWS_WIN_HANN : RTLWS_WIN_RECT;
         else if (!strcmp(argv[i], "--precision") && i + 1 < argc) {
@@ -72,6 +77,7 @@ int main(int argc, char** argv)
             else { fprintf(stderr, "--output f32|db|payload\n"); return 2; }
         } else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
+    if (per_dev < 1 || per_dev > 4) { fprintf(stderr, "--shards-per-device 1..4\n"); return 2; }
     if (frames < 0 || k < 1 || launches < 1 || warmup < 0) { fprintf(stderr, "bad --frames / --k / --launches\n"); return 2; }
     if (plan_only) {                       /* the partition alone: no device is touched */
         if (devices < 1) { fprintf(stderr, "--plan-only needs --devices D\n"); return 2; }
@@ -94,6 +100,11 @@ int main(int argc, char** argv)
     if (rehearsal > 0) {
         n = rehearsal;
         ids = (int*)calloc((size_t)n, sizeof(int));       /* all zero: device 0 */
+    } else if (per_dev > 1) {
+        const int ndev = n;
+        n = ndev * per_dev;
+        ids = (int*)calloc((size_t)n, sizeof(int));
+        for (g = 0; g < n; g++) ids[g] = g / per_dev;     /* contiguous frame ranges stay on one device */
     }
     m = rtlws_multi_open(n, ids, &d, frames, f64);
     if (!m) { fprintf(stderr, "rtlws_multi_open failed: %s\n", rtlws_last_error()); return 3; }
@@ -112,10 +123,10 @@ int main(int argc, char** argv)
     total = (double)frames * launches / (wall_ms * 1e-3);
     bytes_per_frame = (double)rtlws_multi_frame_bytes(m) + (double)rtlws_multi_row_bytes(m) / k;
     printf("{\"metric\": \"spectra/s (%d-pt IQ frames)\", \"workload\": \"multi_batch\", \"frames_used\": %ld, \"n_fft\": %d, \"k_avg\": %d, "
-           "\"cic_r\": %d, \"precision\": \"%s\", \"output\": \"%s\", \"shards\": %d, \"devices_of_host\": %d, "
+           "\"cic_r\": %d, \"precision\": \"%s\", \"output\": \"%s\", \"shards\": %d, \"shards_per_device\": %d, \"devices_of_host\": %d, "
            "\"rehearsal_all_on_device0\": %s, \"launches\": %d, \"warmup\": %d, \"wall_ms\": %.4f, "
            "\"spectra_per_s_total\": %.1f, \"algorithmic_bytes_per_frame\": %.0f, \"per_shard\": [",
-           nfft, frames, nfft, k, cic, precision, output_name, n, rtlws_device_count(), rehearsal > 0 ? "true" : "false",
+           nfft, frames, nfft, k, cic, precision, output_name, n, rehearsal > 0 ? 0 : per_dev, rtlws_device_count(), rehearsal > 0 ? "true" : "false",
            launches, warmup, wall_ms, total, bytes_per_frame);
     for (g = 0; g < n; g++) {
         const double ev_s = st[g].event_ms * 1e-3 / launches;

@@ -59,13 +59,16 @@ def test_more_shards_than_rows_and_empty_batch(engine, built):
 def test_driver_line_on_this_box(built):
     """rtlws_multi_batch on whatever devices the box has, and the 2-shard rehearsal on device 0."""
     exe = os.path.join(built.LIB_DIR, "rtlws_multi_batch")
-    for extra, shards in (([], built.device_count()), (["--shards-on-device0", "2"], 2)):
+    for extra, shards in (([], built.device_count()), (["--shards-on-device0", "2"], 2),
+                          (["--shards-per-device", "2"], 2 * built.device_count())):
         out = subprocess.run([exe, "--frames", "8192", "--launches", "20", "--warmup", "20"] + extra,
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         r = json.loads(out.stdout)
         assert r["shards"] == shards and r["frames_used"] == 8192 and r["spectra_per_s_total"] > 1e6
-        assert r["rehearsal_all_on_device0"] == bool(extra)
+        assert r["rehearsal_all_on_device0"] == ("--shards-on-device0" in extra)
+        if "--shards-per-device" in extra:
+            assert [s["device"] for s in r["per_shard"]] == [g // 2 for g in range(shards)]
         assert sum(s["frames"] for s in r["per_shard"]) == 8192
         assert all(s["event_ms_per_launch"] > 0 and s["spectra_per_s"] > 0 for s in r["per_shard"])
 

@@ -712,7 +712,8 @@ def multi_batch_main(args):
     bytes_per_dev = r["algorithmic_bytes_per_frame"] * per_gpu
     achieved = bytes_per_dev / (worst * 1e-3) / 1e9
     line = {"metric": "spectra/s (1024-pt IQ frames)", "value": r["spectra_per_s_total"], "unit": "spectra/s",
-            "n_gpus": r["shards"], "steps": args.steps, "warmup": r["warmup"], "ms_per_step": r["wall_ms"] / args.steps,
+            "n_gpus": r["shards"] // max(1, args.shards_per_device), "steps": args.steps, "warmup": r["warmup"],
+            "ms_per_step": r["wall_ms"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": MULTI_BATCH_WORKLOAD, "n_fft": r["n_fft"], "k_avg": r["k_avg"],
                        "frames_per_step": r["frames_used"], "frames_per_gpu": per_gpu, "shards_per_device": q,

@@ -84,3 +84,9 @@ def test_bench_wrapper_line(built):
     assert r["config"]["workload"] == "multi_batch" and r["n_gpus"] == built.device_count() and r["scaling"] == "weak"
     assert r["config"]["frames_per_gpu"] == 8192 and r["config"]["frames_per_step"] == 8192 * r["n_gpus"]
     assert 0 < r["roofline"]["frac"] < 1 and len(r["per_device"]) == r["n_gpus"] and r["value"] > 1e6
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "multi_batch", "--steps", "50",
+                          "--frames", "8192", "--shards-per-device", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r2 = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r2["n_gpus"] == built.device_count() and len(r2["per_device"]) == 2 * r2["n_gpus"]
+    assert r2["config"]["shards_per_device"] == 2 and "not one kernel's duration" in r2["roofline"]["frac_clock"]

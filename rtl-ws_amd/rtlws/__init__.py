@@ -22,7 +22,8 @@ ROOT = os.path.dirname(_PKG)                       # rtl-ws_amd/
 LIB_DIR = os.path.join(ROOT, "lib")
 # RTLWS_HIP_LIB selects an experiment build (make variant ...); default: the product library
 HIP_LIB = os.environ.get("RTLWS_HIP_LIB") or os.path.join(LIB_DIR, "librtlws_hip.so")
-AMD_LIB = os.path.join(LIB_DIR, "librtlws_amd.so")
+# RTLWS_AMD_LIB: an instrumented build of the C host layer (tests/tools/asan_host_cpu.sh)
+AMD_LIB = os.environ.get("RTLWS_AMD_LIB") or os.path.join(LIB_DIR, "librtlws_amd.so")
 CBB_LIB = os.path.join(LIB_DIR, "librtlws_cbb.so")       # include/cbb_main.h
 SYNTH_LIB = os.path.join(LIB_DIR, "librtlws_synth.so")   # synthetic rtl_sensor.h + signal_source.h
 

@@ -82,6 +82,14 @@ def test_no_gpu_fails_loudly(built):
         built.Spectrum(1024)
     rc, _, _ = built.cic_decimate(8, np.zeros((64, 2), dtype=np.uint8))
     assert rc == -3
+    A = built.amd_lib()
+    A.rtlws_stream_open.restype = ctypes.c_void_p
+    A.rtlws_stream_open.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    d = built.make_desc(1024)
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_double, ctypes.c_void_p)(lambda *a: None)
+    assert not A.rtlws_stream_open(0, ctypes.byref(d), 128, 3, ctypes.cast(cb, ctypes.c_void_p), None)
+    with pytest.raises(RuntimeError):
+        built.MultiBatch(d, 1024, device_ids=[0, 0])
 
 
 def test_void_entry_points_do_not_kill_the_host_without_a_gpu(built):

@@ -39,6 +39,22 @@ def test_sharded_batch_equals_one_launch(engine, built, prec, shards, K, window,
     assert all(s.event_ms > 0 and s.wall_ms >= s.event_ms * 0.5 for s in stats) and wall >= max(s.wall_ms for s in stats) - 1e-9
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_sharded_cic_fused_batch(engine, built, f64):
+    """configs[3]'s shape through the sharded path: raw IQ, CIC 8:1 + 2048-point, 3 shards on device 0."""
+    from rtlws import synth
+    N, R, B = 2048, 8, 50
+    iq = synth.tone_noise_iq(B * R, N, seed=9).reshape(B, N * R, 2)
+    desc = built.make_desc(N, 1, "cu8", "rect", "power_sum", R)
+    mb = built.MultiBatch(desc, B, device_ids=[0, 0, 0], f64=f64)
+    mb.upload(iq)
+    mb.run(2)
+    got = mb.download()
+    mb.close()
+    want = engine.spectra(iq, N, cic_r=R, f64=f64)
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
 def test_more_shards_than_rows_and_empty_batch(engine, built):
     from rtlws import synth
     iq = synth.tone_noise_iq(2, 1024, seed=1)

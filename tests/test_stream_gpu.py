@@ -221,3 +221,34 @@ def test_stream_on_the_last_device(built, oracle):
     L.rtlws_stream_flush(s)
     L.rtlws_stream_close(s)
     assert rel_err(np.concatenate(got), oracle.batch_spectra_u8(iq, N, nthreads=4), EPS_K1).max() <= TOL
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_stream_of_raw_iq_through_the_fused_decimator(built, oracle, prec):
+    """BASELINE.json configs[3] as a live stream: sensor buffers of raw cmplx_u8, CIC 8:1 and a
+    2048-point spectrum in one launch per chunk (desc.cic_r = 8), in f32 and in the reference's f64."""
+    from rtlws import synth
+    L = _lib(built)
+    N, R, frames_per_chunk, nchunks = 2048, 8, 16, 6
+    iq = synth.tone_noise_iq(frames_per_chunk * nchunks * R, N, seed=5).reshape(frames_per_chunk * nchunks, N * R, 2)
+    got = []
+    ctype = C.c_double if prec == "f64" else C.c_float
+
+    @CB
+    def cb(rows, nrows, first_frame, lat, user):
+        got.append(np.ctypeslib.as_array(C.cast(rows, C.POINTER(ctype)), shape=(nrows, N)).copy())
+
+    desc = built.make_desc(N, cic_r=R, flags=built.FLAG_F64 if prec == "f64" else 0)
+    s = L.rtlws_stream_open(0, C.byref(desc), frames_per_chunk, 3, cb, None)
+    assert s
+    for c in range(nchunks):
+        chunk = np.ascontiguousarray(iq[c * frames_per_chunk:(c + 1) * frames_per_chunk])
+        assert L.rtlws_stream_push(s, chunk.ctypes.data_as(C.c_void_p), 1) == 0
+    L.rtlws_stream_flush(s)
+    L.rtlws_stream_close(s)
+    ref = oracle.batch_spectra_cic_u8(iq, N, R, nthreads=8)
+    rows = np.concatenate(got)
+    if prec == "f64":
+        assert rel_err(rows, ref, EPS_STRICT).max() <= 1e-10
+    else:
+        assert rel_err(rows, ref, EPS_K1).max() <= TOL

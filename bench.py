@@ -434,6 +434,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     elapsed = time.perf_counter() - t0
     # (after the clock has stopped: releasing the probe's queue and pinned words takes ~1 ms)
     sclk_ghz, probe_s = eng.clock_probe_stop(probe) if probe is not None else (None, None)
+    per_rank_sclk = gather_ranks(torch, dist, sclk_ghz or 0.0, ctx.get("reduce_device", device))
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
@@ -510,6 +511,7 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                                                       "all": per_rank_own},
                                   "event_ms_per_step": {"min": min(per_rank_ev), "max": max(per_rank_ev),
                                                         "all": per_rank_ev},
+                                  "sclk_ghz": {"min": min(per_rank_sclk), "max": max(per_rank_sclk), "all": per_rank_sclk},
                                   "note": "own = each rank's wall clock around its launches + synchronise, before "
                                           "the closing barrier; ms_per_step is the MAX over ranks incl. the barrier"}
 

@@ -406,8 +406,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     torch.cuda.synchronize()
     # one sleeping wavefront on a queue of its own reads the shader-clock and 100 MHz counters when the
     # timed region starts and when it ends: the clock THESE launches ran at (include/rtlws_hip.h,
-    # rtlws_clock_probe_*).  Started before t0; told to leave once the launches have drained, which the
-    # closing device synchronise then waits for (one poll, ~0.5 us).
+    # rtlws_clock_probe_*).  Started before t0; told to leave by a write-value packet behind the last launch,
+    # which the closing device synchronise then waits for (one poll, ~0.5 us).
     probe = eng.clock_probe_start() if ctx.get("clock_probe", True) else None
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
@@ -418,11 +418,9 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     L.rtlws_event_record(ev1, eng.h, stream)
     tC = time.perf_counter()
     if probe is not None:
-        tstream.synchronize()
-        tD = time.perf_counter()
-        eng.clock_probe_signal(probe)
-    else:
-        tD = tC
+        # the device itself tells the probe to leave once the launches above have drained
+        eng.clock_probe_signal_on_stream(probe, stream)
+    tD = time.perf_counter()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0        # this rank's launches, before waiting for the others
     if os.environ.get("RTLWS_BENCH_DEBUG"):

@@ -282,6 +282,9 @@ int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float
  * it); *seconds = the interval.  start: NULL on failure; stop: 0 / -1 / -3 (the handle is consumed). */
 void* rtlws_clock_probe_start(rtlws_engine* e);
 void rtlws_clock_probe_signal(void* probe);
+/* The same signal, given by the device: written when everything enqueued on `stream` so far has
+ * completed (a stream write-value packet), so the host need not wait for the stream first.  0 / -1 / -3. */
+int rtlws_clock_probe_signal_on_stream(void* probe, void* stream);
 int rtlws_clock_probe_stop(void* probe, double* sclk_ghz, double* seconds);
 
 /* Device-to-device copy on `stream` (delay-line upkeep of chained kernels). */

@@ -999,6 +999,18 @@ void rtlws_clock_probe_signal(void* probe)
     if (p) __atomic_store_n(p->stop, 1, __ATOMIC_RELEASE);
 }
 
+int rtlws_clock_probe_signal_on_stream(void* probe, void* stream)
+{
+    g_err.clear();
+    rtlws_clock_probe* p = reinterpret_cast<rtlws_clock_probe*>(probe);
+    if (!p) { g_err = "rtlws_clock_probe_signal_on_stream: null probe"; return -1; }
+    HIP_TRY(hipSetDevice(p->e->device), -3);
+    // the command processor writes the flag when it reaches this packet, i.e. once everything enqueued on
+    // `stream` before it has completed: no host round trip between the last launch and the probe's exit
+    HIP_TRY(hipStreamWriteValue32(pick_stream(p->e, stream), p->stop, 1, 0), -3);
+    return 0;
+}
+
 int rtlws_clock_probe_stop(void* probe, double* sclk_ghz, double* seconds)
 {
     g_err.clear();

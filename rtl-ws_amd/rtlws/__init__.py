@@ -70,7 +70,8 @@ HIP_SYMBOLS = [
     "rtlws_fm_demod", "rtlws_copy_d2d", "rtlws_spectra_batch_f64", "rtlws_payload_from_sums_f64",
     "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64",
     "rtlws_queue_create", "rtlws_queue_destroy", "rtlws_queue_wait_event", "rtlws_event_create_blocking",
-    "rtlws_clock_probe_start", "rtlws_clock_probe_signal", "rtlws_clock_probe_stop",
+    "rtlws_clock_probe_start", "rtlws_clock_probe_signal", "rtlws_clock_probe_signal_on_stream",
+    "rtlws_clock_probe_stop",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
@@ -172,6 +173,7 @@ def hip_lib():
         L.rtlws_clock_probe_start.restype = vp
         L.rtlws_clock_probe_signal.argtypes = [vp]
         L.rtlws_clock_probe_signal.restype = None
+        L.rtlws_clock_probe_signal_on_stream.argtypes = [vp, vp]
         L.rtlws_clock_probe_stop.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rtlws_spectra_grid.argtypes = [vp, C.POINTER(SpectraDesc), l, C.POINTER(i),
                                          C.POINTER(i), C.POINTER(i)]
@@ -335,6 +337,9 @@ class Engine:
 
     def clock_probe_signal(self, probe):
         hip_lib().rtlws_clock_probe_signal(probe)
+
+    def clock_probe_signal_on_stream(self, probe, stream=None):
+        self._chk(hip_lib().rtlws_clock_probe_signal_on_stream(probe, stream), "rtlws_clock_probe_signal_on_stream")
 
     def clock_probe_stop(self, probe):
         """(sclk_ghz, seconds) of the interval since clock_probe_start."""

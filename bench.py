@@ -401,6 +401,9 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     torch.cuda.synchronize()
 
     ev0, ev1 = L.rtlws_event_create(), L.rtlws_event_create()
+    # (a handle creates its HIP event on its first record: do that here, not inside the timed region)
+    L.rtlws_event_record(ev0, eng.h, stream)
+    L.rtlws_event_record(ev1, eng.h, stream)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

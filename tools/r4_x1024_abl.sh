@@ -1,5 +1,8 @@
 #!/bin/bash
-# ablations of spectrum_f64_1024x.hip on the f64-arithmetic / f32-row workload + its counters
+# ablations of spectrum_f64_1024x.hip on the f64-arithmetic / f32-row workload + its counters.
+# Build the variants first (here, before gpurun):
+#   for v in NOLDS NOSTORE NOLOAD; do make -C rtl-ws_amd variant NAME=x_$(echo $v | tr A-Z a-z) EXTRA=-DRTLWS_F64_ABL_$v; done
+#   make -C rtl-ws_amd variant NAME=x_nomem EXTRA="-DRTLWS_F64_ABL_NOLOAD -DRTLWS_F64_ABL_NOSTORE"
 OUT=gpurun_out/r04_x1024_ablations.txt; : > $OUT
 V=$PWD/rtl-ws_amd/lib/variants
 run() { RTLWS_HIP_LIB=$2 timeout -k 10 120 python3 bench.py --workload $3 --steps 1500 --no-cpu-baseline --no-extra 2>/dev/null | \

@@ -315,3 +315,19 @@ def test_cbb_init_without_a_gpu_leaves_the_server_alive(built):
         "L.cbb_close(); print('alive')\n" % (ROOT, os.path.join(ROOT, "rtl-ws_amd")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and out.stdout.strip().endswith("alive"), out.stderr[-2000:]
+
+
+def test_public_headers_are_strict_c99(tmp_path):
+    """The boundary is a C-ABI: every header under include/ compiles on its own as strict C99
+    (no C++-isms, no torch / HIP types in a signature)."""
+    import subprocess
+    for h in sorted(os.listdir(INCLUDE)):
+        if not h.endswith(".h"):
+            continue
+        src = tmp_path / ("t_" + h[:-2] + ".c")
+        src.write_text('#include "%s"\nint main(void) { return 0; }\n' % h)
+        out = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", INCLUDE, "-c", str(src),
+                              "-o", os.devnull], capture_output=True, text=True)
+        assert out.returncode == 0, (h, out.stderr)
+        code = re.sub(r"/\*.*?\*/", "", open(os.path.join(INCLUDE, h)).read(), flags=re.S)
+        assert "hipStream_t" not in code and "hipError_t" not in code and "at::" not in code, h

@@ -67,6 +67,11 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
     const int t = threadIdx.x;
     const int K = KONE ? 1 : p.k_avg;
     const long ngroups = p.ngroups;
+#ifdef RTLWS_X_STAMP     // diagnostic build (tools/r5_wave_timeline.py): per-wavefront stamps in the head of its last row
+    const unsigned long long stamp_real0 = wall_clock64(), stamp_clk0 = clock64();
+    long stamp_row = -1;
+    unsigned long long stamp_rows = 0;
+#endif
 
     unsigned raw[16];
     auto load_raw = [&](long frame) {
@@ -217,7 +222,27 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
                 }
             }
         }
+#ifdef RTLWS_X_STAMP
+        stamp_row = g;
+        ++stamp_rows;
+#endif
     }
+#ifdef RTLWS_X_STAMP
+    // {start, end (100 MHz), start, end (shader clocks), HW_ID, XCC_ID, rows, workgroup}; HW_ID: wave [3:0],
+    // SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
+    if (t == 0 && stamp_row >= 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.out) + stamp_row * N * (ROWF32 ? 4 : 8));
+        st[0] = stamp_real0;
+        st[1] = wall_clock64();
+        st[2] = stamp_clk0;
+        st[3] = clock64();
+        st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        st[6] = stamp_rows;
+        st[7] = blockIdx.x;
+    }
+#endif
 }
 
 template <int OUT, bool ROWF32>

@@ -90,6 +90,17 @@ DEF_KERNEL64(k_lshladd64, I8(LSHLADD64))
 #define FMAC64(r) "v_fmac_f64_e32 " #r ", %8, %8\n"
 #define CVT64U(r) "v_cvt_f64_u32_e32 " #r ", %9\n"
 #define CVT64F(r) "v_cvt_f64_f32_e32 " #r ", %9\n"
+// dependent chains: the same register 8 times (latency), two registers alternating
+#define I8_DEP1(op) op(%0) op(%0) op(%0) op(%0) op(%0) op(%0) op(%0) op(%0)
+#define I8_DEP2(op) op(%0) op(%1) op(%0) op(%1) op(%0) op(%1) op(%0) op(%1)
+#define I8_DEP4(op) op(%0) op(%1) op(%2) op(%3) op(%0) op(%1) op(%2) op(%3)
+DEF_KERNEL64(k_fma64_dep1, I8_DEP1(FMA64))
+DEF_KERNEL64(k_fma64_dep2, I8_DEP2(FMA64))
+DEF_KERNEL64(k_fma64_dep4, I8_DEP4(FMA64))
+DEF_KERNEL64(k_add64_dep1, I8_DEP1(ADD64))
+// an f64 stream with one 32-bit integer instruction after every four (the product kernel's mix)
+#define MIX5(a, b, c, d) FMA64(a) FMA64(b) FMA64(c) FMA64(d) "v_add_u32_e32 %9, 1, %9\n"
+DEF_KERNEL64(k_fma64_mix, MIX5(%0, %1, %2, %3) MIX5(%4, %5, %6, %7))
 DEF_KERNEL64(k_fma64, I8(FMA64))
 DEF_KERNEL64(k_add64, I8(ADD64))
 DEF_KERNEL64(k_mul64, I8(MUL64))
@@ -111,7 +122,7 @@ void run(const char* name, kern_t k, float* out)
     printf("%-14s", name);
     const char* only = getenv("VALUBENCH_ONLY");
     if (only && !strstr(name, only)) return;
-    for (int wps : {1, 2, 4, 8}) {
+    for (int wps : {1, 2, 3, 4, 8}) {
         const int blocks = 256 * 4 * wps, iters = 2000;
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f);
@@ -134,7 +145,8 @@ int main()
     run("fmac_e32", k_fmac, out); run("fmac_literal", k_fmac_lit, out); run("fma_vop3", k_fma_vop3, out);
     run("fma_vop3_neg", k_fma_neg, out); run("fmamk", k_fmamk, out); run("cvt_f32_i32", k_cvt, out);
     run("pk_add_f32", k_pkadd, out); run("pk_mul_f32", k_pkmul, out); run("pk_fma_f32", k_pkfma, out); run("mov_b64", k_mov64, out); run("lshl_add_u64", k_lshladd64, out);
-    run("fma_f64", k_fma64, out); run("add_f64", k_add64, out); run("mul_f64", k_mul64, out); run("fmac_f64", k_fmac64, out);
+    run("fma_f64", k_fma64, out); run("fma_f64_dep1", k_fma64_dep1, out); run("fma_f64_dep2", k_fma64_dep2, out); run("fma_f64_dep4", k_fma64_dep4, out);
+    run("add_f64_dep1", k_add64_dep1, out); run("fma_f64_mix4+1", k_fma64_mix, out); run("add_f64", k_add64, out); run("mul_f64", k_mul64, out); run("fmac_f64", k_fmac64, out);
     run("cvt_f64_u32", k_cvt64u, out); run("cvt_f64_f32", k_cvt64f, out);
     run("cvt_ubyte0", k_cvtub0, out); run("cvt_ubyte1", k_cvtub1, out); run("perm_b32", k_perm, out); run("and_or_b32", k_andor, out); run("mul_lo_u32", k_mullo, out); run("bfe_u32", k_bfe, out); run("cndmask", k_cndmask, out);
     run("add_u32", k_addu32, out); run("add_u32_sdwa", k_sdwa, out); run("mov_b32", k_mov, out);

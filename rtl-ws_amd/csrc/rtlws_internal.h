@@ -123,7 +123,7 @@ constexpr int f64_fused_lds_bytes(int n_fft) { return 16 * f64_fused_lds_elems(n
 // 8 wavefronts per CU (2 per SIMD) at every size: 8 / 4 / 2 workgroups
 constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
 // rectangular 1024-point cmplx_u8 frames: the one-transposition kernel (engine option f64_x1024)
-hipError_t launch_spectra_f64_1024x(const SpectraParamsF64&, int blocks, hipStream_t);
+hipError_t launch_spectra_f64_1024x(const SpectraParamsF64&, int blocks, int waves, hipStream_t);
 hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_2048(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);

@@ -76,6 +76,7 @@ struct EngineOpts {
     int f64_fused = 1;           // RTLWS_F64_FUSED=0: f64 batches stay on the row-per-workgroup kernel
     int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
     int f64_x1024 = 1;           // RTLWS_F64_X1024=0: rectangular 1024-point u8 frames stay on the two-transposition kernel
+    int f64_x_waves = 0;         // RTLWS_F64_X_WAVES: wavefronts per workgroup of that kernel: 0 = by batch size, 1, 8
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
     int cic_round = 0;           // RTLWS_CIC_ROUND=1|2|4: LDS staging depth where R fits it
 };
@@ -394,6 +395,7 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.f64_fused = env_int("RTLWS_F64_FUSED", 1);
     e->opt.f64_blocks_per_cu = env_int("RTLWS_F64_BLOCKS_PER_CU", 0);
     e->opt.f64_x1024 = env_int("RTLWS_F64_X1024", 1);
+    e->opt.f64_x_waves = env_int("RTLWS_F64_X_WAVES", 0);
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -428,6 +430,7 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
+    else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
     else {
@@ -446,6 +449,7 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
     if (k == "f64_fused") return e->opt.f64_fused;
     if (k == "f64_blocks_per_cu") return e->opt.f64_blocks_per_cu;
     if (k == "f64_x1024") return e->opt.f64_x1024;
+    if (k == "f64_x_waves") return e->opt.f64_x_waves;
     if (k == "cic_direct") return e->opt.cic_direct;
     if (k == "cic_round") return e->opt.cic_round;
     if (k == "cu_count") return e->cu_count;
@@ -840,8 +844,14 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
         // rectangular 1024-point cmplx_u8 frames: one LDS transposition instead of two
         // (its dB / payload epilogues beside K-frame accumulators would spill: those stay where they were)
         if (d->n_fft == 1024 && in_kind == rtlws::IN_CU8 && !p.window && e->opt.f64_x1024 && p.twxa &&
-            (d->output == RTLWS_OUT_POWER_SUM || d->k_avg == 1))
-            err = rtlws::launch_spectra_f64_1024x(p, (int)blocks, st);
+            (d->output == RTLWS_OUT_POWER_SUM || d->k_avg == 1)) {
+            // batches with at least four rows per wavefront: one eight-wavefront workgroup per CU whose
+            // wavefronts take the workgroup's rows one at a time (spectrum_f64_1024x.hip, WAVES)
+            int waves = e->opt.f64_x_waves;
+            if (waves == 0) waves = (p.ngroups >= 32L * e->cu_count) ? 8 : 1;
+            if (waves == 8) blocks = e->cu_count;
+            err = rtlws::launch_spectra_f64_1024x(p, (int)blocks, waves, st);
+        }
         else switch (d->n_fft) {
         case 1024: err = rtlws::launch_spectra_f64_fused_1024(p, in_kind, (int)blocks, st, e->device); break;
         case 2048: err = rtlws::launch_spectra_f64_fused_2048(p, in_kind, (int)blocks, st, e->device); break;

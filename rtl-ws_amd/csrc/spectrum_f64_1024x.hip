@@ -57,16 +57,44 @@ __device__ __forceinline__ void swap_rows32(unsigned& a, unsigned& b)
     b = r[1];
 }
 
-template <int OUT, bool KONE, bool ROWF32>
-__global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF64 p)
+// WAVES = 1: one wavefront per workgroup, output rows dealt statically (row = workgroup + i * grid) -- small
+// batches and the drop-in calls.  WAVES > 1: ONE workgroup of WAVES wavefronts per CU (WAVES / 4 per SIMD),
+// the workgroup's rows (b + i * grid) handed to its wavefronts one at a time through a counter in LDS.  Why
+// (profiles/r05_wave_timeline_2_per_simd.txt): the SIMD arbitrates its vector pipe by age, the older of two
+// co-resident wavefronts runs at 0.95 of its solo rate and the younger gets the leftover slots -- with rows dealt
+// statically the older one left after 122 of 198 k cycles and the younger finished its last 21 rows alone, at
+// the solo rate (3 640 cycles per row against 2 820 for the pair).  Nothing but the row-to-wavefront map differs:
+// no barrier in the frame loop (the wavefronts share no LDS data), results bit-identical.
+template <int OUT, bool KONE, bool ROWF32, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectra_f64_1024x(const SpectraParamsF64 p)
 {
     constexpr int N = 1024;
     static_assert(!(ROWF32 && OUT == OUT_PAYLOAD), "payload rows are bytes in either form");
-    extern __shared__ __attribute__((aligned(16))) double2 ldsd[];
+    static_assert(WAVES == 1 || WAVES % 4 == 0, "whole wavefronts per SIMD");
+    extern __shared__ __attribute__((aligned(16))) double2 lds_all[];
+    double2* const ldsd = lds_all + (WAVES == 1 ? 0 : (threadIdx.x >> 6) * (17 * 64));     // this wavefront's own slice
+    unsigned* const row_counter = reinterpret_cast<unsigned*>(lds_all + WAVES * 17 * 64);    // (WAVES > 1)
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 63;
     const int K = KONE ? 1 : p.k_avg;
     const long ngroups = p.ngroups;
+    // row index i of this workgroup <-> output row blockIdx.x + i * gridDim.x; mine: how many it owns
+    const long mine = ((long)blockIdx.x < ngroups) ? (ngroups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    long ri = WAVES == 1 ? 0 : (long)(threadIdx.x >> 6);       // the first WAVES indices are dealt statically
+    if constexpr (WAVES > 1) {
+        if (threadIdx.x == 0) *row_counter = WAVES;
+        __syncthreads();                                        // the only barrier of the kernel
+    }
+    // next index: WAVES = 1 counts, WAVES > 1 takes the workgroup's next undone row (lane 0's LDS atomic, broadcast)
+    auto claim = [&](long cur) -> long {
+        if constexpr (WAVES == 1) {
+            return cur + 1;
+        } else {
+            unsigned v = 0;
+            if (t == 0) v = __hip_atomic_fetch_add(row_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return (long)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        }
+    };
 #ifdef RTLWS_X_STAMP     // diagnostic build (tools/r5_wave_timeline.py): per-wavefront stamps in the head of its last row
     const unsigned long long stamp_real0 = wall_clock64(), stamp_clk0 = clock64();
     long stamp_row = -1;
@@ -84,7 +112,7 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
         for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j + t);
 #endif
     };
-    if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
+    if (ri < mine) load_raw(((long)blockIdx.x + ri * gridDim.x) * K);
 
     // lane constants, resident for the life of the (persistent) workgroup
     f2 twA[8], twB[16];
@@ -99,7 +127,9 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
 
     const int wp = t >> 4, wc = t & 15;         // writer side of the transposition: lane (p, c)
 
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    while (ri < mine) {
+        const long g = (long)blockIdx.x + ri * gridDim.x;
+        const long ri_next = claim(ri);
         double acc[16];
         double wdc = 0.0;
 #pragma unroll
@@ -131,8 +161,7 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
             }
             {
                 long nf = frame + 1;
-                if (kf + 1 == K) nf = (g + gridDim.x) * K;
-                if (nf >= ngroups * K) nf = frame;        // in bounds, result unused
+                if (kf + 1 == K) nf = ri_next < mine ? ((long)blockIdx.x + ri_next * gridDim.x) * K : frame;   // (in bounds, result unused)
                 load_raw(nf);
             }
 
@@ -152,24 +181,37 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
 
             // ---- pass A: radix-16 over r with the geometric pre-twiddle (W_64^p)^r absorbed;
             // slot s holds index q = rev16(s)
+#ifndef RTLWS_F64_ABL_NOPASSA     // (energy-attribution builds, tools/r5_energy_abl.sh: wrong results, same data flow)
             fft_last<16>(v, 0, twA);
+#endif
             // inner twiddles W_256^(c q) x the lane constant W_1024^(p c) x 1/128
+#ifndef RTLWS_F64_ABL_NOTWB
 #pragma unroll
             for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twB[s]);
+#else
+#pragma unroll
+            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(v[s].x), "+v"(v[s].y));
+#endif
 
             // ---- the one transposition: (p, c; q) -> lane 4 q + p, sixteen c contiguous (rows
             // padded 16 -> 17 double2: conflict-free ds_write_b128 and ds_read_b128)
 #ifndef RTLWS_F64_ABL_NOLDS      // (timing-only build without the LDS traffic)
-            __syncthreads();   // one wavefront per workgroup: no s_barrier, only the LDS ordering
+            // the slice is this wavefront's own: ordering within the wavefront only, never an s_barrier
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int s = 0; s < 16; ++s) ldsd[17 * (4 * rev16(s) + wp) + wc] = v[s];
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = ldsd[17 * t + c];
 #endif
 
             // ---- pass B: radix-16 over c; slot s holds q' = rev16(s): bin k = 64 q' + t
+#ifndef RTLWS_F64_ABL_NOPASSB
             fft16_sel(v);
+#endif
 
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -226,6 +268,7 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
         stamp_row = g;
         ++stamp_rows;
 #endif
+        ri = ri_next;
     }
 #ifdef RTLWS_X_STAMP
     // {start, end (100 MHz), start, end (shader clocks), HW_ID, XCC_ID, rows, workgroup}; HW_ID: wave [3:0],
@@ -240,32 +283,56 @@ __global__ __launch_bounds__(64, 2) void spectra_f64_1024x(const SpectraParamsF6
         st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         st[6] = stamp_rows;
-        st[7] = blockIdx.x;
+        st[7] = blockIdx.x * WAVES + (threadIdx.x >> 6);
     }
 #endif
 }
 
-template <int OUT, bool ROWF32>
+// LDS: one 16 x 17 x 64-byte transposition slice per wavefront (+ the row counter)
+constexpr size_t x_lds_bytes(int waves) { return (size_t)waves * 16 * 17 * 64 + (waves > 1 ? 16 : 0); }
+
+template <int OUT, bool ROWF32, int WAVES>
 static hipError_t launch_x_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
-    constexpr size_t lds_bytes = 16 * 17 * 64;
+    constexpr size_t lds_bytes = x_lds_bytes(WAVES);
+    if constexpr (lds_bytes > 65536) {      // once per instantiation and device
+        static bool done[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!done[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT, true, ROWF32, WAVES>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e == hipSuccess && OUT == OUT_SUM)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, false, ROWF32, WAVES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            done[dev] = true;
+        }
+    }
     if (p.k_avg == 1) {
-        hipLaunchKernelGGL((spectra_f64_1024x<OUT, true, ROWF32>), dim3(blocks), dim3(64), lds_bytes, st, p);
+        hipLaunchKernelGGL((spectra_f64_1024x<OUT, true, ROWF32, WAVES>), dim3(blocks), dim3(64 * WAVES), lds_bytes, st, p);
     } else if constexpr (OUT == OUT_SUM) {     // (dB / payload beside K-frame accumulators: spectrum_f64_fused.hip)
-        hipLaunchKernelGGL((spectra_f64_1024x<OUT, false, ROWF32>), dim3(blocks), dim3(64), lds_bytes, st, p);
+        hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, false, ROWF32, WAVES>), dim3(blocks), dim3(64 * WAVES), lds_bytes, st, p);
     } else {
         return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_spectra_f64_1024x(const SpectraParamsF64& p, int blocks, hipStream_t st)
+template <int WAVES>
+static hipError_t launch_x_w(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
     switch (p.out_mode) {
-    case OUT_SUM: return p.rows_f32 ? launch_x_k<OUT_SUM, true>(p, blocks, st) : launch_x_k<OUT_SUM, false>(p, blocks, st);
-    case OUT_DB: return p.rows_f32 ? launch_x_k<OUT_DB, true>(p, blocks, st) : launch_x_k<OUT_DB, false>(p, blocks, st);
-    default: return launch_x_k<OUT_PAYLOAD, false>(p, blocks, st);
+    case OUT_SUM: return p.rows_f32 ? launch_x_k<OUT_SUM, true, WAVES>(p, blocks, st) : launch_x_k<OUT_SUM, false, WAVES>(p, blocks, st);
+    case OUT_DB: return p.rows_f32 ? launch_x_k<OUT_DB, true, WAVES>(p, blocks, st) : launch_x_k<OUT_DB, false, WAVES>(p, blocks, st);
+    default: return launch_x_k<OUT_PAYLOAD, false, WAVES>(p, blocks, st);
     }
+}
+
+// waves = 1: `blocks` one-wavefront workgroups; waves = 8: `blocks` workgroups of eight wavefronts (one per CU)
+hipError_t launch_spectra_f64_1024x(const SpectraParamsF64& p, int blocks, int waves, hipStream_t st)
+{
+    return waves == 8 ? launch_x_w<8>(p, blocks, st) : launch_x_w<1>(p, blocks, st);
 }
 
 }  // namespace rtlws

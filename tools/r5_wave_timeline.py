@@ -83,12 +83,19 @@ def analyse(buf, label):
     return end.max()
 
 
-for per_cu in [int(a) for a in sys.argv[1:]] or [8]:
-    eng.set_option("f64_blocks_per_cu", per_cu)
+# arguments: workgroups per CU of the one-wavefront form (1 .. 16), or w8 for the eight-wavefront workgroups
+for arg in sys.argv[1:] or ["8"]:
+    if arg.startswith("w"):
+        eng.set_option("f64_x_waves", int(arg[1:]))
+        per_cu = arg
+    else:
+        eng.set_option("f64_x_waves", 1)
+        per_cu = int(arg)
+        eng.set_option("f64_blocks_per_cu", per_cu)
     for i in range(600):      # settle the clock governor
         eng.spectra_batch_f64(desc, src[i % 3].data_ptr(), FRAMES, dst[i % 3].data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    analyse(dst[(600 - 1) % 3], "f64_blocks_per_cu %d, steady state (launch 600 of 600)" % per_cu)
+    analyse(dst[(600 - 1) % 3], "f64_blocks_per_cu %s, steady state (launch 600 of 600)" % per_cu)
     eng.spectra_batch_f64(desc, src[0].data_ptr(), FRAMES, dst[0].data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    analyse(dst[0], "f64_blocks_per_cu %d, isolated launch" % per_cu)
+    analyse(dst[0], "f64_blocks_per_cu %s, isolated launch" % per_cu)

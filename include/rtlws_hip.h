@@ -78,9 +78,28 @@ int rtlws_engine_device(const rtlws_engine* e);
  *   "blocks_per_cu"     [RTLWS_BLOCKS_PER_CU]     > 0: workgroups per CU of the f32 fused kernels
  *   "f64_fused"         [RTLWS_F64_FUSED]         0: f64 batches on the row-per-workgroup kernel
  *   "f64_blocks_per_cu" [RTLWS_F64_BLOCKS_PER_CU]
+ *   "f64_x1024"         [RTLWS_F64_X1024]         0: rectangular 1024-point cmplx_u8 frames stay on the
+ *                                                 two-transposition f64 kernel
+ *   "f64_x_waves"       [RTLWS_F64_X_WAVES]       wavefronts per workgroup of the one-transposition f64 kernel:
+ *                                                 0 by batch size (8 from 32 rows per CU on), 1, 8
  *   "cic_direct"        [RTLWS_CIC_DIRECT]        1: per-lane loads for every CIC factor but 8
  *   "cic_round"         [RTLWS_CIC_ROUND]         1 | 2 | 4: LDS staging depth of the generic factors
- * set: 0, or -1 for an unknown name.  get: the value ("cu_count" is readable too), -2 if unknown. */
+ *   "split"             [RTLWS_SPLIT]             Q = 1 .. 8 (default 1): rtlws_spectra_batch / _f64 cut a batch's
+ *       rows into Q contiguous ranges of whole K-groups and launch them concurrently -- range 0 on the
+ *       caller's stream, the others on Q - 1 engine-owned queues forked from it and joined back into it
+ *       by events, so the caller still orders against its own stream only; rows bit-identical to one
+ *       launch; batches of fewer than 16 rows per CU and range are not cut.  The queues and events are
+ *       created when the option is set (never on a launch path: a cut batch is capturable).  MEASURED
+ *       (one MI355X, 65 536 x 1024-point frames, profiles/r05_split.txt): Q = 2 is SLOWER than one launch
+ *       -- 0.41 against 0.45 of the HBM roofline in f64 arithmetic, 0.53 against 0.64 in f32: the fork and
+ *       the join are cross-queue dependencies that cost more per batch than the overlapped fill and drain
+ *       phases win -- and with more HIP streams in the process than hardware queues (4 by default; five at
+ *       Q = 3 under bench.py) a batch takes 14 ms.  The overlap pays only for INDEPENDENT batches on
+ *       independent queues (rtlws_multi.h, shards per device); the option stays for callers who can
+ *       measure their own case.  With Q > 1 an engine's launches must come from one thread at a time.
+ * set: 0, -1 for an unknown name, -3 if the queues of "split" cannot be created.  get: the value ("cu_count" is
+ * readable too), -2 if unknown.  An option must not be changed while another thread launches on the same engine
+ * (the launch paths read the options without the engine's lock). */
 int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value);
 int rtlws_engine_get_option(const rtlws_engine* e, const char* name);
 
@@ -89,7 +108,9 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name);
  * therefore not legal inside a hipGraph capture).  After this, batch launches
  * for that size only enqueue a kernel and may be captured.  0 / -1 / -3. */
 int rtlws_engine_prepare(rtlws_engine* e, int n_fft);
-/* The same for rtlws_spectra_batch_f64's tables (2 <= n_fft <= 8192). */
+/* The same for rtlws_spectra_batch_f64's tables (2 <= n_fft <= 8192); it also raises the dynamic-LDS limit of
+ * every instantiation of that size that needs more than 64 KiB (hipFuncSetAttribute, once per instantiation
+ * and device), which the first launch of such an instantiation would otherwise do. */
 int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft);
 
 /* Last error text of the calling thread ("" when none). */

@@ -231,9 +231,10 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
 // (MI355X_MICROARCH.md, DVFS): d(memtime) / d(memrealtime) x 100 MHz is the clock the chip actually
 // ran at over that interval -- the interval of the timed launches, not of another launch series.
 // It sleeps between polls (s_sleep: no issue slots, no memory traffic but one 4-byte read per ~0.5 us)
-// and ALWAYS terminates: on the stop flag, or after max_polls polls.
+// and ALWAYS terminates: on the stop flag, after max_ticks of the 100 MHz counter (a bound in TIME: a poll is a
+// sleep plus a system-scope load whose latency depends on what else runs), or after max_polls polls.
 __global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsigned long long* out,
-                                                         int max_polls)
+                                                         int max_polls, unsigned long long max_ticks)
 {
     const unsigned long long c0 = clock64(), r0 = wall_clock64();
     if (threadIdx.x == 0) {                 // tells the host it is resident: the caller's clock starts after this
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsign
         __builtin_amdgcn_s_sleep(16);       // ~0.5 us between polls
         ++polls;
         if (__hip_atomic_load(stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) break;   // past every cache
+        if (wall_clock64() - r0 > max_ticks) break;
     }
     if (threadIdx.x == 0) {
         out[0] = clock64() - c0;
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsign
 
 hipError_t launch_clock_probe(const int* stop_flag, unsigned long long* out, int max_polls, hipStream_t st)
 {
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, stop_flag, out, max_polls);
+    // 10 s of the 100 MHz counter, whatever a poll costs
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, stop_flag, out, max_polls, 1000000000ull);
     return hipGetLastError();
 }
 

@@ -79,7 +79,9 @@ struct EngineOpts {
     int f64_x_waves = 0;         // RTLWS_F64_X_WAVES: wavefronts per workgroup of that kernel: 0 = by batch size, 1, 8
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
     int cic_round = 0;           // RTLWS_CIC_ROUND=1|2|4: LDS staging depth where R fits it
+    int split = 1;               // RTLWS_SPLIT: a batch's rows as this many concurrent launches (engine-owned queues)
 };
+constexpr int kMaxSplit = 8;
 
 struct rtlws_engine {
     int device = 0;
@@ -88,6 +90,13 @@ struct rtlws_engine {
     EngineOpts opt;
     std::mutex mu;
     std::map<int, Tables> tables;   // by n_fft (fused) or -n_fft (direct)
+    // option "split": the side queues ranges 1 .. Q-1 of a batch are launched on, the event the caller's
+    // stream forks them at and the events it joins them with; created when the option is set (never on a
+    // launch path: a launch only enqueues, so it may be captured into a hipGraph)
+    hipStream_t split_q[kMaxSplit - 1] = {};
+    hipEvent_t split_fork = nullptr;
+    hipEvent_t split_join[kMaxSplit - 1] = {};
+    int split_ready = 0;            // side queues that exist
 };
 
 namespace {
@@ -360,6 +369,54 @@ int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// option "split" = Q: make the Q - 1 side queues and the fork / join events exist (engine mutex held)
+int split_prepare(rtlws_engine* e, int q)
+{
+    if (q > kMaxSplit) q = kMaxSplit;
+    HIP_TRY(hipSetDevice(e->device), -3);
+    if (q > 1 && !e->split_fork) HIP_TRY(hipEventCreateWithFlags(&e->split_fork, hipEventDisableTiming), -3);
+    while (e->split_ready < q - 1) {
+        const int i = e->split_ready;
+        HIP_TRY(hipStreamCreateWithFlags(&e->split_q[i], hipStreamNonBlocking), -3);
+        HIP_TRY(hipEventCreateWithFlags(&e->split_join[i], hipEventDisableTiming), -3);
+        e->split_ready = i + 1;
+    }
+    return 0;
+}
+
+// How many concurrent launches a batch of `rows` output rows is cut into: the option, but never ranges of
+// fewer than two rows per resident wavefront slot (a short range is all fill and drain).
+int split_count(const rtlws_engine* e, long rows)
+{
+    int q = e->opt.split;
+    if (q > e->split_ready + 1) q = e->split_ready + 1;
+    while (q > 1 && rows / q < 16L * e->cu_count) --q;
+    return q < 1 ? 1 : q;
+}
+
+// Range r of Q: rows [r * rows / Q, (r + 1) * rows / Q) -- contiguous, whole K-groups (a row IS a K-group),
+// balanced to one row.  Range 0 runs on the caller's stream `st`, ranges 1 .. Q-1 on the engine's side
+// queues, forked from `st` by an event and joined back into it by one event each: to the caller the batch
+// is still ordered on `st` alone.  launch(r, row0, nrows, stream) enqueues one range.
+// hipStreamWaitEvent dereferences its stream argument: the hipStreamLegacy token ((hipStream_t)1) crashes it
+// (ROCm 7.2).  This library is built with the legacy default-stream semantics, where stream 0 IS that stream.
+hipStream_t waitable(hipStream_t st) { return st == hipStreamLegacy ? nullptr : st; }
+
+template <class F>
+hipError_t split_launch(rtlws_engine* e, hipStream_t st, int Q, long rows, F&& launch)
+{
+    hipError_t err = hipEventRecord(e->split_fork, waitable(st));
+    for (int r = 1; r < Q && err == hipSuccess; ++r) {
+        const long r0 = r * rows / Q, r1 = (r + 1) * rows / Q;
+        err = hipStreamWaitEvent(e->split_q[r - 1], e->split_fork, 0);
+        if (err == hipSuccess) err = launch(r, r0, r1 - r0, e->split_q[r - 1]);
+        if (err == hipSuccess) err = hipEventRecord(e->split_join[r - 1], e->split_q[r - 1]);
+    }
+    if (err == hipSuccess) err = launch(0, 0L, rows / Q, st);
+    for (int r = 1; r < Q && err == hipSuccess; ++r) err = hipStreamWaitEvent(waitable(st), e->split_join[r - 1], 0);
+    return err;
+}
+
 }  // namespace
 
 extern "C" {
@@ -398,10 +455,17 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.f64_x_waves = env_int("RTLWS_F64_X_WAVES", 0);
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
+    e->opt.split = env_int("RTLWS_SPLIT", 1);
+    if (e->opt.split < 1) e->opt.split = 1;
+    if (e->opt.split > kMaxSplit) e->opt.split = kMaxSplit;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_err("hipStreamCreate", err);
         delete e;
+        return nullptr;
+    }
+    if (e->opt.split > 1 && split_prepare(e, e->opt.split) != 0) {
+        rtlws_engine_destroy(e);
         return nullptr;
     }
     return e;
@@ -413,6 +477,12 @@ void rtlws_engine_destroy(rtlws_engine* e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tables) free_tables(kv.second);
+    for (int i = 0; i < e->split_ready; ++i) {
+        (void)hipStreamSynchronize(e->split_q[i]);
+        (void)hipStreamDestroy(e->split_q[i]);
+        (void)hipEventDestroy(e->split_join[i]);
+    }
+    if (e->split_fork) (void)hipEventDestroy(e->split_fork);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -433,6 +503,11 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
+    else if (k == "split") {
+        const int q = value < 1 ? 1 : (value > kMaxSplit ? kMaxSplit : value);
+        if (split_prepare(e, q) != 0) return -3;
+        e->opt.split = q;
+    }
     else {
         g_err = "rtlws_engine_set_option: unknown option '" + k + "'";
         return -1;
@@ -452,6 +527,7 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
     if (k == "f64_x_waves") return e->opt.f64_x_waves;
     if (k == "cic_direct") return e->opt.cic_direct;
     if (k == "cic_round") return e->opt.cic_round;
+    if (k == "split") return e->opt.split;
     if (k == "cu_count") return e->cu_count;
     return -2;
 }
@@ -483,7 +559,44 @@ int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft)
         return -1;
     }
     Tables tb;
-    return get_tables_f64(e, n_fft, &tb);
+    if (get_tables_f64(e, n_fft, &tb) != 0) return -3;
+    // Instantiations that need more than 64 KiB of LDS raise their limit with hipFuncSetAttribute, once per
+    // instantiation and device: do that for every instantiation of this size NOW (launchers called with an
+    // empty grid set the attribute and enqueue nothing), so that a launch -- under hipGraph capture too --
+    // makes no other runtime call than the launch.
+    HIP_TRY(hipSetDevice(e->device), -3);
+    rtlws::SpectraParamsF64 p;
+    std::memset(&p, 0, sizeof p);
+    p.n_fft = n_fft;
+    static const double dummy_window = 0.0;
+    hipError_t err = hipSuccess;
+    for (int k_avg = 1; k_avg <= 2 && err == hipSuccess; ++k_avg)
+        for (int out = rtlws::OUT_SUM; out <= rtlws::OUT_PAYLOAD && err == hipSuccess; ++out)
+            for (int rows_f32 = 0; rows_f32 <= 1 && err == hipSuccess; ++rows_f32) {
+                p.k_avg = k_avg;
+                p.out_mode = out;
+                p.rows_f32 = rows_f32 && out != rtlws::OUT_PAYLOAD;
+                if (n_fft == 1024 && (out == rtlws::OUT_SUM || k_avg == 1)) {
+                    p.window = nullptr;
+                    err = rtlws::launch_spectra_f64_1024x(p, 0, 8, e->stream);
+                }
+                if (n_fft == 4096)
+                    for (int w = 0; w <= 1 && err == hipSuccess; ++w) {
+                        p.window = w ? &dummy_window : nullptr;
+                        for (int in_kind : {(int)rtlws::IN_CU8, (int)rtlws::IN_CS32, (int)rtlws::IN_RF32, (int)rtlws::IN_CU8_CIC8,
+                                            (int)rtlws::IN_CU8_CIC10, (int)rtlws::IN_CU8_CIC12})
+                            if (err == hipSuccess) err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, 0, e->stream, e->device);
+                    }
+            }
+    if (err == hipSuccess && n_fft > 4096) {
+        p.ngroups = 0;
+        for (int in = RTLWS_IN_CU8; in <= RTLWS_IN_RF32 && err == hipSuccess; ++in) err = rtlws::launch_spectra_f64(p, in, e->stream, e->device);
+    }
+    if (err != hipSuccess) {
+        set_err("rtlws_engine_prepare_f64: hipFuncSetAttribute", err);
+        return -3;
+    }
+    return 0;
 }
 
 const char* rtlws_last_error(void) { return g_err.c_str(); }
@@ -597,7 +710,7 @@ int rtlws_queue_wait_event(rtlws_engine* e, void* stream, void* ev)
     if (!x || !x->ev) { g_err = "rtlws_queue_wait_event: event was never recorded"; return -1; }
     if (x->device != e->device) { g_err = "rtlws_queue_wait_event: event belongs to another device"; return -1; }
     HIP_TRY(hipSetDevice(e->device), -3);
-    HIP_TRY(hipStreamWaitEvent(pick_stream(e, stream), x->ev, 0), -3);
+    HIP_TRY(hipStreamWaitEvent(waitable(pick_stream(e, stream)), x->ev, 0), -3);
     return 0;
 }
 
@@ -741,19 +854,36 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
 
     HIP_TRY(hipSetDevice(e->device), -3);
     hipStream_t st = pick_stream(e, stream);
-    hipError_t err;
-    if (fused) {
-        const int blocks = fused_blocks(e, d->n_fft, p.ngroups, in_kind, p.window != nullptr,
-                                        d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
-        if (use_v2(e, d->n_fft, in_kind, d->k_avg)) err = rtlws::launch_spectra_fused_v2(p, blocks, st);
-        else switch (d->n_fft) {
-        case 1024: err = rtlws::launch_spectra_fused_1024(p, in_kind, blocks, st); break;
-        case 2048: err = rtlws::launch_spectra_fused_2048(p, in_kind, blocks, st); break;
-        default: err = rtlws::launch_spectra_fused_4096(p, in_kind, blocks, st); break;
+    auto launch = [&](const rtlws::SpectraParams& pp, hipStream_t s) -> hipError_t {
+        if (fused) {
+            const int blocks = fused_blocks(e, d->n_fft, pp.ngroups, in_kind, pp.window != nullptr,
+                                            d->k_avg == 1 && rtlws::fused_kone_kind(in_kind), d->k_avg);
+            if (use_v2(e, d->n_fft, in_kind, d->k_avg)) return rtlws::launch_spectra_fused_v2(pp, blocks, s);
+            switch (d->n_fft) {
+            case 1024: return rtlws::launch_spectra_fused_1024(pp, in_kind, blocks, s);
+            case 2048: return rtlws::launch_spectra_fused_2048(pp, in_kind, blocks, s);
+            default: return rtlws::launch_spectra_fused_4096(pp, in_kind, blocks, s);
+            }
         }
+        // the direct kernel sums R bytes itself
+        return rtlws::launch_spectra_direct(pp, in_kind >= rtlws::IN_CU8_CIC8 ? (int)rtlws::IN_CU8 : in_kind, s);
+    };
+    hipError_t err;
+    const int Q = fused ? split_count(e, p.ngroups) : 1;
+    if (Q <= 1) {
+        err = launch(p, st);
     } else {
-        if (in_kind >= rtlws::IN_CU8_CIC8) in_kind = rtlws::IN_CU8;     // the direct kernel sums R bytes itself
-        err = rtlws::launch_spectra_direct(p, in_kind, st);
+        // option "split": the rows as Q concurrent launches (their fill and drain phases overlap)
+        const size_t in_row = (size_t)d->k_avg * d->n_fft * p.cic_r *
+                              (d->input == RTLWS_IN_CU8 ? 2 : d->input == RTLWS_IN_CS32 ? 8 : 4);
+        const size_t out_row = (size_t)d->n_fft * (d->output == RTLWS_OUT_PAYLOAD_U8 ? 1 : 4);
+        err = split_launch(e, st, Q, p.ngroups, [&](int, long r0, long n, hipStream_t s) {
+            rtlws::SpectraParams pp = p;
+            pp.in = static_cast<const char*>(d_in) + r0 * in_row;
+            pp.out = static_cast<char*>(d_out) + r0 * out_row;
+            pp.ngroups = n;
+            return launch(pp, s);
+        });
     }
     if (err != hipSuccess) {
         set_err("spectra kernel launch", err);
@@ -833,32 +963,47 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
 
     HIP_TRY(hipSetDevice(e->device), -3);
     hipStream_t st = pick_stream(e, stream);
-    hipError_t err;
     // the fused throughput kernel (spectrum_f64_fused.hip) where it exists; option f64_fused = 0
     // keeps everything on the row-per-workgroup kernel (A/B runs, tests)
-    if (rtlws::f64_fused_kind(d->n_fft, in_kind) && e->opt.f64_fused && aligned) {
+    const bool fused = rtlws::f64_fused_kind(d->n_fft, in_kind) && e->opt.f64_fused && aligned;
+    auto launch = [&](const rtlws::SpectraParamsF64& pp, hipStream_t s) -> hipError_t {
+        if (!fused) return rtlws::launch_spectra_f64(pp, d->input, s, e->device);
         int per_cu = rtlws::f64_fused_blocks_per_cu(d->n_fft);
         if (e->opt.f64_blocks_per_cu > 0 && e->opt.f64_blocks_per_cu <= 2 * per_cu) per_cu = e->opt.f64_blocks_per_cu;   // experiments only
         long blocks = (long)e->cu_count * per_cu;
-        if (blocks > p.ngroups) blocks = p.ngroups;
+        if (blocks > pp.ngroups) blocks = pp.ngroups;
         // rectangular 1024-point cmplx_u8 frames: one LDS transposition instead of two
         // (its dB / payload epilogues beside K-frame accumulators would spill: those stay where they were)
-        if (d->n_fft == 1024 && in_kind == rtlws::IN_CU8 && !p.window && e->opt.f64_x1024 && p.twxa &&
+        if (d->n_fft == 1024 && in_kind == rtlws::IN_CU8 && !pp.window && e->opt.f64_x1024 && pp.twxa &&
             (d->output == RTLWS_OUT_POWER_SUM || d->k_avg == 1)) {
             // batches with at least four rows per wavefront: one eight-wavefront workgroup per CU whose
             // wavefronts take the workgroup's rows one at a time (spectrum_f64_1024x.hip, WAVES)
             int waves = e->opt.f64_x_waves;
-            if (waves == 0) waves = (p.ngroups >= 32L * e->cu_count) ? 8 : 1;
+            if (waves == 0) waves = (pp.ngroups >= 32L * e->cu_count) ? 8 : 1;
             if (waves == 8) blocks = e->cu_count;
-            err = rtlws::launch_spectra_f64_1024x(p, (int)blocks, waves, st);
+            return rtlws::launch_spectra_f64_1024x(pp, (int)blocks, waves, s);
         }
-        else switch (d->n_fft) {
-        case 1024: err = rtlws::launch_spectra_f64_fused_1024(p, in_kind, (int)blocks, st, e->device); break;
-        case 2048: err = rtlws::launch_spectra_f64_fused_2048(p, in_kind, (int)blocks, st, e->device); break;
-        default: err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, (int)blocks, st, e->device); break;
+        switch (d->n_fft) {
+        case 1024: return rtlws::launch_spectra_f64_fused_1024(pp, in_kind, (int)blocks, s, e->device);
+        case 2048: return rtlws::launch_spectra_f64_fused_2048(pp, in_kind, (int)blocks, s, e->device);
+        default: return rtlws::launch_spectra_f64_fused_4096(pp, in_kind, (int)blocks, s, e->device);
         }
+    };
+    hipError_t err;
+    const int Q = fused ? split_count(e, p.ngroups) : 1;
+    if (Q <= 1) {
+        err = launch(p, st);
     } else {
-        err = rtlws::launch_spectra_f64(p, d->input, st, e->device);
+        const size_t in_row = (size_t)d->k_avg * d->n_fft * p.cic_r *
+                              (d->input == RTLWS_IN_CU8 ? 2 : d->input == RTLWS_IN_CS32 ? 8 : 4);
+        const size_t out_row = (size_t)d->n_fft * (d->output == RTLWS_OUT_PAYLOAD_U8 ? 1 : p.rows_f32 ? 4 : 8);
+        err = split_launch(e, st, Q, p.ngroups, [&](int, long r0, long n, hipStream_t s) {
+            rtlws::SpectraParamsF64 pp = p;
+            pp.in = static_cast<const char*>(d_in) + r0 * in_row;
+            pp.out = static_cast<char*>(d_out) + r0 * out_row;
+            pp.ngroups = n;
+            return launch(pp, s);
+        });
     }
     if (err != hipSuccess) {
         set_err("f64 spectra kernel launch", err);

@@ -221,6 +221,7 @@ static hipError_t launch_f64_in(const SpectraParamsF64& p, hipStream_t st, int d
             ready.fetch_or(bit, std::memory_order_release);
         }
     }
+    if (p.ngroups <= 0) return hipSuccess;   // rtlws_engine_prepare_f64: the attribute only, nothing enqueued
     hipLaunchKernelGGL((spectra_f64<IN>), dim3((unsigned)p.ngroups), dim3(256), lds_bytes, st, p);
     return hipGetLastError();
 }

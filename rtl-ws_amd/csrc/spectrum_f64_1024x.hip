@@ -309,6 +309,7 @@ static hipError_t launch_x_k(const SpectraParamsF64& p, int blocks, hipStream_t 
             done[dev] = true;
         }
     }
+    if (blocks <= 0) return hipSuccess;      // rtlws_engine_prepare_f64: the attribute only, nothing enqueued
     if (p.k_avg == 1) {
         hipLaunchKernelGGL((spectra_f64_1024x<OUT, true, ROWF32, WAVES>), dim3(blocks), dim3(64 * WAVES), lds_bytes, st, p);
     } else if constexpr (OUT == OUT_SUM) {     // (dB / payload beside K-frame accumulators: spectrum_f64_fused.hip)

@@ -360,6 +360,7 @@ static hipError_t launch_f64f_one(const SpectraParamsF64& p, int blocks, hipStre
             ready.fetch_or(bit, std::memory_order_release);
         }
     }
+    if (blocks <= 0) return hipSuccess;      // rtlws_engine_prepare_f64: the attribute only, nothing enqueued
     hipLaunchKernelGGL((spectra_f64_fused<N, IN, WIN, OUT, KONE, ROWF32>), dim3(blocks), dim3(N / 16), lds_bytes, st, p);
     return hipGetLastError();
 }

@@ -77,14 +77,70 @@ def test_cpu_baseline_block_bookkeeping(oracle):
     from rtlws import synth
     wl = bench.WORKLOADS["batched_1024pt_64k_frames"]
     dev_in = torch.from_numpy(synth.tone_noise_iq(256, 1024, seed=5))
-    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 256, budget_scale=0.02)
+    mask = len(os.sched_getaffinity(0))
+    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 256, budget_scale=0.02, quota=None)
     assert out["unit"] == "spectra/s" and out["kind"] == "port" and out["nproc"] == os.cpu_count()
-    assert out["cores"] == len(os.sched_getaffinity(0)) and out["value"] > 0     # the whole mask, uncapped
+    assert out["affinity_mask_cores"] == mask and out["cgroup_cpu_quota"] is None
+    assert [r["cores"] for r in out["runs"]] == sorted({1, mask})
+    # `value` is the fastest run and `cores` the thread count that produced it
+    best = max(out["runs"], key=lambda r: r["value"])
+    assert out["value"] == best["value"] and out["cores"] == best["cores"] and out["value"] > 0
     assert out["one_thread"]["cores"] == 1 and out["one_thread"]["value"] > 0
+    # a faked quota smaller than the mask: timed with 1, the quota and the mask
+    if mask >= 3:
+        out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 256, budget_scale=0.02, quota=2.0)
+        assert [r["cores"] for r in out["runs"]] == [1, 2, mask] and out["cgroup_cpu_quota"] == 2.0
+        best = max(out["runs"], key=lambda r: r["value"])
+        assert (out["value"], out["cores"]) == (best["value"], best["cores"])
     wl = bench.WORKLOADS["cic8_block_sums"]
     dev_in = torch.from_numpy(synth.uniform_iq(8, 2048 * 8, seed=6))
     out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 8, budget_scale=0.02)
     assert out["unit"] == "samples/s" and out["cores"] == 1 and out["value"] > 0
+
+
+def test_cpu_quota_is_read_from_the_cgroup(tmp_path):
+    """the job's CPU share is read (cpu.max of cgroup v2, the cfs pair of v1, the
+    smallest over the process's cgroup and its ancestors), not inferred."""
+    import bench
+    root = tmp_path / "cg"
+    (root / "jobs" / "j1").mkdir(parents=True)
+    proc = tmp_path / "cgroup"
+    proc.write_text("0::/jobs/j1\n")
+    assert bench.cpu_quota(str(root), str(proc)) is None                       # nothing to read
+    (root / "cpu.max").write_text("max 100000\n")
+    assert bench.cpu_quota(str(root), str(proc)) is None                       # unlimited
+    (root / "jobs" / "j1" / "cpu.max").write_text("1600000 100000\n")
+    assert bench.cpu_quota(str(root), str(proc)) == 16.0
+    (root / "jobs" / "cpu.max").write_text("800000 100000\n")                  # a tighter ancestor wins
+    assert bench.cpu_quota(str(root), str(proc)) == 8.0
+    # cgroup v1: cpu controller mounted under <root>/cpu
+    root1 = tmp_path / "cg1"
+    (root1 / "cpu" / "pod").mkdir(parents=True)
+    proc1 = tmp_path / "cgroup1"
+    proc1.write_text("4:memory:/x\n1:cpu,cpuacct:/pod\n")
+    (root1 / "cpu" / "pod" / "cpu.cfs_quota_us").write_text("-1\n")
+    (root1 / "cpu" / "pod" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cpu_quota(str(root1), str(proc1)) is None
+    (root1 / "cpu" / "pod" / "cpu.cfs_quota_us").write_text("250000\n")
+    assert bench.cpu_quota(str(root1), str(proc1)) == 2.5
+    assert bench.cpu_thread_counts(256, 16.0) == [1, 16, 256]
+    assert bench.cpu_thread_counts(256, 2.5) == [1, 3, 256]
+    assert bench.cpu_thread_counts(8, None) == [1, 8] and bench.cpu_thread_counts(8, 64.0) == [1, 8]
+    assert bench.cpu_thread_counts(1, 0.5) == [1]
+
+
+def test_headline_is_the_reference_arithmetic_workload():
+    """the driver parses the default line -- it must be configs[1] in the reference's
+    arithmetic (f64, src/spectrum.c:21,28,54-58) at the contract's 6 144 B per spectrum; the f32 kernel on the
+    same frames rides along as the fast mode."""
+    import bench
+    assert bench.HEADLINE == "batched_1024pt_64k_frames_f64c_f32o" and bench.precision_of(bench.HEADLINE) == "f64c_f32o"
+    assert bench.WORKLOADS[bench.HEADLINE] == (1024, 1, "rect", "power_sum", 0, 65536)
+    assert bench.algorithmic_bytes_per_frame(1024, 1, 0, "power_sum", f64=False) == 6144      # f32 rows
+    assert bench.FAST_MODE in bench.EXTRA_WORKLOADS and bench.precision_of(bench.FAST_MODE) == "f32"
+    assert bench.HEADLINE not in bench.EXTRA_WORKLOADS
+    assert all(n in bench.WORKLOADS and 2 <= q <= 8 for n, q in bench.EXTRA_SPLIT)
+    assert bench.parity_bounds_for(bench.HEADLINE)["max_rel_err_floor1e-9"] <= 6e-8
 
 
 def test_cpu_baseline_block_windowed_and_cic_cases(oracle, monkeypatch):
@@ -99,7 +155,7 @@ def test_cpu_baseline_block_windowed_and_cic_cases(oracle, monkeypatch):
     monkeypatch.setattr(oracle, "batch_spectra_cic_u8", lambda h, n, r, **kw: (seen.append(("cic", n, r, kw)), real_cic(h, n, r, **kw))[1])
     wl = bench.WORKLOADS["hann_4096pt_k8_db"]
     dev_in = torch.from_numpy(synth.tone_noise_iq(64, 4096, seed=5))
-    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 64, budget_scale=0.01)
+    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 64, budget_scale=0.01, quota=None)
     assert out["value"] > 0 and out["one_thread"]["value"] > 0 and "Hann, mean dB" in out["sample"] and "K = 8" in out["sample"]
     assert seen and all(k[0] == "u8" and k[1] == 4096 and k[2]["K"] == 8 for k in seen)
     assert all(np.allclose(k[2]["window"], synth.hann(4096)) for k in seen)
@@ -107,7 +163,7 @@ def test_cpu_baseline_block_windowed_and_cic_cases(oracle, monkeypatch):
     seen.clear()
     wl = bench.WORKLOADS["cic8_2048pt"]
     dev_in = torch.from_numpy(synth.uniform_iq(16, 2048 * 8, seed=6))
-    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 16, budget_scale=0.01)
+    out = bench.cpu_baseline_block(np, oracle, wl, dev_in, 16, budget_scale=0.01, quota=None)
     assert out["value"] > 0 and "CIC 8:1 first" in out["sample"]
     assert seen and all(k[0] == "cic" and k[1] == 2048 and k[2] == 8 and k[3]["window"] is None for k in seen)
 

@@ -65,6 +65,22 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
     assert runs[0]["parity"] == runs[1]["parity"]             # same seed, same kernel: identical statistics
 
 
+def test_run_workload_with_the_split_option(ctx, monkeypatch):
+    """bench.py --split Q: the batch's rows as Q concurrent launches (engine option "split"); the line says that
+    its event time is the batch's, the engine's option is restored, parity holds and the energy leg reports joules."""
+    import bench
+    monkeypatch.setattr(bench, "SETTLE_LAUNCHES", 40)
+    monkeypatch.setattr(bench, "ENERGY_LAUNCHES", 200)
+    for name in (bench.HEADLINE, bench.FAST_MODE):
+        r = bench.run_workload(ctx, name, steps=8, warmup=0, sets=2, frames_override=16384, split=2)
+        assert r["config"]["split"] == 2 and "concurrent launches" in r["roofline"]["frac_clock"]
+        assert "failed" not in r["parity"] and bench.parity_failures(r["parity"], bench.parity_bounds_for(name)) == []
+        assert ctx["eng"].get_option("split") == 1
+        en = r["roofline"].get("energy")
+        if en is not None:                    # (rocm_smi readable on the box)
+            assert en["launches"] == 200 and 0.0 < en["mj_per_launch"] < 1000.0 and 100.0 < en["watts"] < 2000.0
+
+
 def test_run_workload_uniform_input_variant(ctx):
     """SURVEY.md §8d's other input: uniform random bytes (bench.py --input uniform)."""
     import bench

@@ -21,7 +21,10 @@ def test_trace_average_matches_bench_events():
         assert abs(achieved_from_trace / b["roofline"]["achieved"] - 1.0) <= 0.03, f
         assert d["timed_avg_ns"] <= 1e6 * b["ms_per_step"], f
         seen.add(d["workload"])
-    assert "batched_1024pt_64k_frames" in seen           # the headline must be among them
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.HEADLINE in seen and bench.FAST_MODE in seen      # the headline (and the fast mode) must be among them
 
 
 def test_hbm_traffic_is_close_to_algorithmic():

@@ -63,6 +63,10 @@ typedef struct rtlws_engine rtlws_engine;
 /* Number of usable HIP devices (0 when none; never negative). */
 int rtlws_device_count(void);
 
+/* The device's PCI bus id, "0000:05:00.0" (domain:bus:device.function), NUL-terminated into buf[len],
+ * len >= 16: what rtlws_topo.h maps to a NUMA node.  0 / -1 / -3. */
+int rtlws_device_pci_bus_id(int device, char* buf, int len);
+
 /* One engine per device per user: owns a stream and the twiddle/window
  * tables.  Returns NULL (and sets rtlws_last_error) if the device cannot be
  * used -- there is no CPU fallback behind this library. */

@@ -9,15 +9,18 @@
  * pthread and one engine (own HIP stream, own tables) per device, NO collective and no
  * peer access: xGMI is not used.  The host side is plain C over rtlws_hip.h.
  *
- * Lifetime: open (allocates each device's share of the input and of the rows) -> upload
- * (each device thread copies its own range) -> run any number of times (each device thread
- * enqueues `launches` launches of its range on its engine's stream between two HIP events;
- * the threads start together at a barrier) -> download -> close.
+ * Lifetime: open (one thread per shard is created and lives until close: it pins itself to the CPUs
+ * of its device's NUMA node -- rtlws_topo.h -- and THEN creates its engine and allocates its device's
+ * share of the input and of the rows and two pinned staging buffers) -> upload (each shard thread
+ * copies its own range, through its pinned staging buffers) -> run any number of times (each shard
+ * thread enqueues `launches` launches of its range on its engine's stream between two HIP events;
+ * the threads are released together by one broadcast) -> download -> close.
  */
 #ifndef RTLWS_MULTI_H
 #define RTLWS_MULTI_H
 
 #include "rtlws_hip.h"
+#include "rtlws_topo.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -54,6 +57,15 @@ typedef struct rtlws_multi_shard_stats {
 rtlws_multi* rtlws_multi_open(int n_shards, const int* device_ids, const rtlws_spectra_desc* desc,
                               long nframes, int f64);
 int rtlws_multi_shards(const rtlws_multi* m);
+/* Why the last upload / run / download of `m` returned non-zero: "shard g (device d): <call>: <the HIP
+ * shim's text>" of its first failing shard ("" after a success).  The failing call ran on a shard's own
+ * thread, so the CALLER's rtlws_last_error() does not hold it.  m == NULL: the same for the last
+ * rtlws_multi_open of this process that returned NULL. */
+const char* rtlws_multi_error(const rtlws_multi* m);
+/* Where shard g runs: its device's PCI bus id, NUMA node and cpuset as the shard thread found them
+ * (rtlws_topo.h; unknown fields "" / -1 / 0) and the number of CPUs the thread pinned itself to
+ * (0: not pinned -- no NUMA information, or the node's CPUs lie outside the job's mask).  0 / -1. */
+int rtlws_multi_shard_topology(const rtlws_multi* m, int g, rtlws_topo_info* out, int* cpus_pinned);
 /* frames the shards cover: k_avg * (nframes / k_avg) */
 long rtlws_multi_frames(const rtlws_multi* m);
 /* bytes of one input frame / one output row, as the batch API lays them out */

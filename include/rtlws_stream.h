@@ -19,6 +19,7 @@
 #define RTLWS_STREAM_H
 
 #include "rtlws_hip.h"
+#include "rtlws_topo.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,6 +51,11 @@ typedef struct rtlws_stream_stats {
  * RTLWS_FLAG_F64 = the reference's f64 (rtlws_spectra_batch_f64; + RTLWS_FLAG_ROWS_F32: f32 rows).
  * Opening a stream also warms it: tables built, code object loaded, one chunk of mid-scale samples
  * through every ring slot, so the first real chunk has the latency of any other.
+ * NUMA: for the length of the call the CALLING thread is pinned to the CPUs of the device's NUMA node
+ * (rtlws_topo.h) -- the pinned ring slots are allocated and first touched there, and the worker thread,
+ * created meanwhile, inherits that mask and keeps it; the caller's own mask is put back before the call
+ * returns.  A producer that wants its pushes (a memcpy into a ring slot each) local too pins itself the
+ * same way (rtlws_topo_pin_thread; rtl-ws_amd/host/multi_stream_main.c does).
  * NULL on failure (rtlws_last_error). */
 rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
                                 int ring_slots, rtlws_stream_callback cb, void* user);
@@ -73,6 +79,10 @@ int rtlws_stream_push(rtlws_stream* s, const void* iq_host, int block);
 int rtlws_stream_flush(rtlws_stream* s);
 
 void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out);
+
+/* Where the stream's worker thread and pinned slots live: the device's PCI bus id, NUMA node and cpuset
+ * (unknown: "" / -1 / 0) and the number of CPUs the worker is pinned to (0: not pinned).  0 / -1. */
+int rtlws_stream_topology(const rtlws_stream* s, rtlws_topo_info* out, int* cpus_pinned);
 
 void rtlws_stream_close(rtlws_stream* s);
 

@@ -428,6 +428,17 @@ int rtlws_device_count(void)
     return n < 0 ? 0 : n;
 }
 
+int rtlws_device_pci_bus_id(int device, char* buf, int len)
+{
+    g_err.clear();
+    if (!buf || len < 16 || device < 0 || device >= rtlws_device_count()) {
+        g_err = "rtlws_device_pci_bus_id: bad device or buffer (>= 16 bytes)";
+        return -1;
+    }
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, device), -3);
+    return 0;
+}
+
 rtlws_engine* rtlws_engine_create(int device)
 {
     g_err.clear();

@@ -36,6 +36,10 @@
 #include "rtlws_internal.h"
 #include "fft_regs_f64.h"
 
+#ifndef RTLWS_X_LDS_ORDER
+#define RTLWS_X_LDS_ORDER 0
+#endif
+
 namespace rtlws {
 
 using namespace f64;
@@ -78,21 +82,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     const int t = threadIdx.x & 63;
     const int K = KONE ? 1 : p.k_avg;
     const long ngroups = p.ngroups;
-    // row index i of this workgroup <-> output row blockIdx.x + i * gridDim.x; mine: how many it owns
-    const long mine = ((long)blockIdx.x < ngroups) ? (ngroups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-    long ri = WAVES == 1 ? 0 : (long)(threadIdx.x >> 6);       // the first WAVES indices are dealt statically
+    // this workgroup's output rows: blockIdx.x + i * gridDim.x; the first WAVES indices i are dealt statically
+    long g = (long)blockIdx.x + (WAVES == 1 ? 0L : (long)(threadIdx.x >> 6) * gridDim.x);
     if constexpr (WAVES > 1) {
         if (threadIdx.x == 0) *row_counter = WAVES;
         __syncthreads();                                        // the only barrier of the kernel
     }
-    // next index: WAVES = 1 counts, WAVES > 1 takes the workgroup's next undone row (lane 0's LDS atomic, broadcast)
-    auto claim = [&](long cur) -> long {
+    // the row after `cur`: WAVES = 1 strides, WAVES > 1 takes the workgroup's next undone row (lane 0's LDS
+    // atomic, broadcast); >= ngroups: none left
+    auto next_row = [&](long cur) -> long {
         if constexpr (WAVES == 1) {
-            return cur + 1;
+            return cur + gridDim.x;
         } else {
             unsigned v = 0;
             if (t == 0) v = __hip_atomic_fetch_add(row_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return (long)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            return (long)blockIdx.x + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)v) * gridDim.x;
         }
     };
 #ifdef RTLWS_X_STAMP     // diagnostic build (tools/r5_wave_timeline.py): per-wavefront stamps in the head of its last row
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
         for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j + t);
 #endif
     };
-    if (ri < mine) load_raw(((long)blockIdx.x + ri * gridDim.x) * K);
+    if (g < ngroups) load_raw(g * K);
 
     // lane constants, resident for the life of the (persistent) workgroup
     f2 twA[8], twB[16];
@@ -127,9 +131,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 
     const int wp = t >> 4, wc = t & 15;         // writer side of the transposition: lane (p, c)
 
-    while (ri < mine) {
-        const long g = (long)blockIdx.x + ri * gridDim.x;
-        const long ri_next = claim(ri);
+    while (g < ngroups) {
+        const long g_next = next_row(g);
         double acc[16];
         double wdc = 0.0;
 #pragma unroll
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             }
             {
                 long nf = frame + 1;
-                if (kf + 1 == K) nf = ri_next < mine ? ((long)blockIdx.x + ri_next * gridDim.x) * K : frame;   // (in bounds, result unused)
+                if (kf + 1 == K) nf = g_next * K;
+                if (nf >= ngroups * K) nf = frame;        // in bounds, result unused  (this form: the ternary
+                                                          // spelling costs the K > 1 instantiations 12-15 spilled VGPRs)
                 load_raw(nf);
             }
 
@@ -196,7 +201,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             // ---- the one transposition: (p, c; q) -> lane 4 q + p, sixteen c contiguous (rows
             // padded 16 -> 17 double2: conflict-free ds_write_b128 and ds_read_b128)
 #ifndef RTLWS_F64_ABL_NOLDS      // (timing-only build without the LDS traffic)
-            // the slice is this wavefront's own: ordering within the wavefront only, never an s_barrier
+            // the slice is this wavefront's own: ordering within the wavefront only, never an s_barrier.
+            // RTLWS_X_LDS_ORDER 0: wavefront-scope fences (the compiler may spread the writes over pass A's
+            // tail and start pass B under the reads); 2: workgroup-scope fences, i.e. what __syncthreads() is
+            // around its s_barrier -- writes retired (lgkmcnt(0)) before the reads are issued
+#if RTLWS_X_LDS_ORDER == 2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ldsd[17 * (4 * rev16(s) + wp) + wc] = v[s];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = ldsd[17 * t + c];
 #endif
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
         stamp_row = g;
         ++stamp_rows;
 #endif
-        ri = ri_next;
+        g = g_next;
     }
 #ifdef RTLWS_X_STAMP
     // {start, end (100 MHz), start, end (shader clocks), HW_ID, XCC_ID, rows, workgroup}; HW_ID: wave [3:0],

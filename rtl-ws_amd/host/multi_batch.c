@@ -1,6 +1,15 @@
 /* multi_batch.c -- rtlws_multi.h: a device-resident batch sharded over the GPUs of a node,
  * one host pthread + one engine per shard, no collective.  Plain C over
- * include/rtlws_hip.h. */
+ * include/rtlws_hip.h.
+ *
+ * A shard's thread lives as long as the handle.  It pins itself to the CPUs of its device's NUMA node
+ * (rtlws_topo.h) BEFORE it creates its engine and allocates -- device buffers, events, and the two pinned
+ * staging buffers its uploads and downloads go through -- so that on a two-socket node neither the thread
+ * nor the first touch of its pinned memory lands on the far socket.  Commands (upload / run / download)
+ * are posted to all shards at once under one mutex and one broadcast: that IS the start gate, and a
+ * thread that times a run has long made its first HIP calls (a thread's first call costs milliseconds:
+ * a freshly created thread per command, as in round 4, put that inside the timed region). */
+#define _GNU_SOURCE
 #include "rtlws_multi.h"
 
 #include <pthread.h>
@@ -9,14 +18,30 @@
 #include <string.h>
 #include <time.h>
 
+#include "rtlws_topo.h"
+
+enum { CMD_NONE = 0, CMD_INIT, CMD_UPLOAD, CMD_RUN, CMD_DOWNLOAD, CMD_EXIT };
+#define STAGE_BYTES ((size_t)8 << 20)      /* pinned staging buffer: 2 per shard */
+
 struct shard {
-    int device;
+    rtlws_multi* m;
+    int g, device;
     long first_frame, frames;
     rtlws_engine* eng;
     void* d_in;
     void* d_out;
     void* ev0;
     void* ev1;
+    void* h_stage[2];          /* pinned, allocated by the shard's own (pinned) thread */
+    void* stage_ev[2];
+    rtlws_topo_info topo;
+    int cpus_pinned;
+    pthread_t th;
+    int started;
+    long seen;                 /* generation of the last command this thread took */
+    int rc;
+    double event_ms, wall_ms;
+    char err[256];
 };
 
 struct rtlws_multi {
@@ -26,7 +51,19 @@ struct rtlws_multi {
     long nframes;
     size_t frame_bytes, row_bytes;
     struct shard* sh;
+    /* command mailbox */
+    pthread_mutex_t mu;
+    pthread_cond_t cv_cmd, cv_done;
+    long gen;
+    int cmd, pending, launches;
+    const unsigned char* host_in;
+    unsigned char* host_out;
+    char err[320];             /* "shard g (device d): ..." of the first failing shard of the last command */
 };
+
+/* the text of the last failed rtlws_multi_open (there is no handle to keep it in) */
+static pthread_mutex_t g_open_mu = PTHREAD_MUTEX_INITIALIZER;
+static char g_open_err[352];
 
 int rtlws_multi_partition(long nframes, int k_avg, int shards, int g, long* first_frame, long* frame_count)
 {
@@ -61,11 +98,196 @@ static double now_ms(void)
     return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
 
+/* a failing call happened on THIS (worker) thread: its text is in this thread's rtlws_last_error() and
+ * nowhere the caller can see -- keep it in the shard */
+static int fail(struct shard* s, const char* what, int rc)
+{
+    snprintf(s->err, sizeof s->err, "%s: %s", what, rtlws_last_error());
+    return rc ? rc : -3;
+}
+
+static int launch_once(rtlws_multi* m, struct shard* s)
+{
+    return m->f64 ? rtlws_spectra_batch_f64(s->eng, &m->desc, s->d_in, s->frames, s->d_out, NULL)
+                  : rtlws_spectra_batch(s->eng, &m->desc, s->d_in, s->frames, s->d_out, NULL);
+}
+
+/* pin, then create everything this shard owns -- in that order */
+static int shard_init(struct shard* s)
+{
+    rtlws_multi* m = s->m;
+    int k;
+    rtlws_topo_describe(s->device, NULL, NULL, &s->topo);
+    s->cpus_pinned = rtlws_topo_pin_thread(&s->topo);
+    if (s->cpus_pinned < 0) s->cpus_pinned = 0;            /* could not pin: run where we are */
+    s->eng = rtlws_engine_create(s->device);
+    if (!s->eng) return fail(s, "rtlws_engine_create", -3);
+    /* an empty shard still owns (1-byte) buffers: its launches are no-ops */
+    s->d_in = rtlws_dev_alloc(s->eng, (size_t)s->frames * m->frame_bytes);
+    s->d_out = rtlws_dev_alloc(s->eng, (size_t)(s->frames / m->desc.k_avg) * m->row_bytes);
+    s->ev0 = rtlws_event_create();
+    s->ev1 = rtlws_event_create();
+    if (!s->d_in || !s->d_out || !s->ev0 || !s->ev1) return fail(s, "device buffers / events", -3);
+    for (k = 0; k < 2; k++) {
+        s->h_stage[k] = rtlws_pinned_alloc(STAGE_BYTES);
+        s->stage_ev[k] = rtlws_event_create();
+        if (!s->h_stage[k] || !s->stage_ev[k]) return fail(s, "pinned staging", -3);
+        memset(s->h_stage[k], 0, STAGE_BYTES);             /* first touch here, on the pinned thread */
+    }
+    if (m->f64 ? rtlws_engine_prepare_f64(s->eng, m->desc.n_fft) : rtlws_engine_prepare(s->eng, m->desc.n_fft))
+        return fail(s, "rtlws_engine_prepare", -3);
+    return 0;
+}
+
+static void shard_release(struct shard* s)
+{
+    int k;
+    if (s->eng) {
+        rtlws_stream_sync(s->eng, NULL);
+        rtlws_dev_free(s->eng, s->d_in);
+        rtlws_dev_free(s->eng, s->d_out);
+    }
+    for (k = 0; k < 2; k++) {
+        rtlws_pinned_free(s->h_stage[k]);
+        rtlws_event_destroy(s->stage_ev[k]);
+        s->h_stage[k] = s->stage_ev[k] = NULL;
+    }
+    rtlws_event_destroy(s->ev0);
+    rtlws_event_destroy(s->ev1);
+    rtlws_engine_destroy(s->eng);
+    s->eng = NULL;
+    s->d_in = s->d_out = s->ev0 = s->ev1 = NULL;
+}
+
+/* the caller's (pageable) frames -> pinned staging -> device, two buffers in turn */
+static int shard_upload(struct shard* s, const unsigned char* host)
+{
+    rtlws_multi* m = s->m;
+    const size_t total = (size_t)s->frames * m->frame_bytes;
+    const unsigned char* src = host + (size_t)s->first_frame * m->frame_bytes;
+    size_t off = 0;
+    int k = 0, used[2] = {0, 0};
+    while (off < total) {
+        const size_t n = total - off < STAGE_BYTES ? total - off : STAGE_BYTES;
+        if (used[k] && rtlws_event_sync(s->stage_ev[k])) return fail(s, "upload: event", -3);
+        memcpy(s->h_stage[k], src + off, n);
+        if (rtlws_copy_h2d(s->eng, (unsigned char*)s->d_in + off, s->h_stage[k], n, NULL) ||
+            rtlws_event_record(s->stage_ev[k], s->eng, NULL))
+            return fail(s, "upload: copy", -3);
+        used[k] = 1;
+        off += n;
+        k ^= 1;
+    }
+    if (rtlws_stream_sync(s->eng, NULL)) return fail(s, "upload: sync", -3);
+    return 0;
+}
+
+/* device -> pinned staging -> the caller's rows; the copy of piece i+1 runs under the memcpy of piece i */
+static int shard_download(struct shard* s, unsigned char* host)
+{
+    rtlws_multi* m = s->m;
+    const size_t total = (size_t)(s->frames / m->desc.k_avg) * m->row_bytes;
+    unsigned char* dst = host + (size_t)(s->first_frame / m->desc.k_avg) * m->row_bytes;
+    size_t issued = 0, done = 0;
+    size_t len[2] = {0, 0};
+    int ki = 0, kd = 0, inflight = 0;
+    while (done < total) {
+        while (inflight < 2 && issued < total) {
+            const size_t n = total - issued < STAGE_BYTES ? total - issued : STAGE_BYTES;
+            if (rtlws_copy_d2h(s->eng, s->h_stage[ki], (const unsigned char*)s->d_out + issued, n, NULL) ||
+                rtlws_event_record(s->stage_ev[ki], s->eng, NULL))
+                return fail(s, "download: copy", -3);
+            len[ki] = n;
+            issued += n;
+            ki ^= 1;
+            ++inflight;
+        }
+        if (rtlws_event_sync(s->stage_ev[kd])) return fail(s, "download: event", -3);
+        memcpy(dst + done, s->h_stage[kd], len[kd]);
+        done += len[kd];
+        kd ^= 1;
+        --inflight;
+    }
+    return 0;
+}
+
+static int shard_run(struct shard* s, int launches)
+{
+    rtlws_multi* m = s->m;
+    int i, rc;
+    const double t0 = now_ms();
+    s->event_ms = 0.0;
+    rc = rtlws_event_record(s->ev0, s->eng, NULL);
+    for (i = 0; i < launches && rc == 0; i++) rc = launch_once(m, s);
+    if (rc == 0) rc = rtlws_event_record(s->ev1, s->eng, NULL);
+    if (rc == 0) rc = rtlws_stream_sync(s->eng, NULL);
+    if (rc == 0) s->event_ms = (double)rtlws_event_elapsed_ms(s->ev0, s->ev1);
+    s->wall_ms = now_ms() - t0;
+    return rc ? fail(s, "run", rc) : 0;
+}
+
+static void* shard_main(void* arg)
+{
+    struct shard* s = (struct shard*)arg;
+    rtlws_multi* m = s->m;
+    for (;;) {
+        int cmd, launches, rc = 0;
+        const unsigned char* in;
+        unsigned char* out;
+        pthread_mutex_lock(&m->mu);
+        while (m->gen == s->seen) pthread_cond_wait(&m->cv_cmd, &m->mu);
+        s->seen = m->gen;
+        cmd = m->cmd;
+        launches = m->launches;
+        in = m->host_in;
+        out = m->host_out;
+        pthread_mutex_unlock(&m->mu);
+
+        s->err[0] = 0;
+        s->wall_ms = 0.0;
+        switch (cmd) {
+        case CMD_INIT: rc = shard_init(s); break;
+        case CMD_UPLOAD: { const double t0 = now_ms(); rc = s->frames ? shard_upload(s, in) : 0; s->wall_ms = now_ms() - t0; } break;
+        case CMD_DOWNLOAD: { const double t0 = now_ms(); rc = s->frames ? shard_download(s, out) : 0; s->wall_ms = now_ms() - t0; } break;
+        case CMD_RUN: rc = shard_run(s, launches); break;
+        default: shard_release(s); break;          /* CMD_EXIT: what this thread created, it frees */
+        }
+        s->rc = rc;
+
+        pthread_mutex_lock(&m->mu);
+        if (rc && !m->err[0]) snprintf(m->err, sizeof m->err, "shard %d (device %d): %s", s->g, s->device, s->err);
+        if (--m->pending == 0) pthread_cond_signal(&m->cv_done);
+        pthread_mutex_unlock(&m->mu);
+        if (cmd == CMD_EXIT) return NULL;
+    }
+}
+
+/* post one command to the first `count` shards' threads and wait for all of them; the first failing shard's code */
+static int post(rtlws_multi* m, int count, int cmd, int launches, const void* host_in, void* host_out)
+{
+    int g, rc = 0;
+    if (count < 1) return 0;
+    pthread_mutex_lock(&m->mu);
+    m->err[0] = 0;
+    m->cmd = cmd;
+    m->launches = launches;
+    m->host_in = (const unsigned char*)host_in;
+    m->host_out = (unsigned char*)host_out;
+    m->pending = count;
+    m->gen++;
+    pthread_cond_broadcast(&m->cv_cmd);           /* every shard starts here, together */
+    while (m->pending) pthread_cond_wait(&m->cv_done, &m->mu);
+    for (g = 0; g < count; g++)
+        if (m->sh[g].rc && !rc) rc = m->sh[g].rc;
+    pthread_mutex_unlock(&m->mu);
+    return rc;
+}
+
 rtlws_multi* rtlws_multi_open(int n_shards, const int* device_ids, const rtlws_spectra_desc* desc,
                               long nframes, int f64)
 {
     rtlws_multi* m;
-    int g;
+    int g, started = 0;
     if (!desc || rtlws_spectra_kernel_kind(desc) == 0 || nframes < 0 || n_shards < 0 ||
         (device_ids && n_shards < 1))
         return NULL;
@@ -81,22 +303,31 @@ rtlws_multi* rtlws_multi_open(int n_shards, const int* device_ids, const rtlws_s
     m->nframes = nframes - nframes % desc->k_avg;        /* whole K-groups */
     m->frame_bytes = frame_bytes_of(desc);
     m->row_bytes = row_bytes_of(desc, m->f64);
+    pthread_mutex_init(&m->mu, NULL);
+    pthread_cond_init(&m->cv_cmd, NULL);
+    pthread_cond_init(&m->cv_done, NULL);
     for (g = 0; g < n_shards; g++) {
         struct shard* s = &m->sh[g];
+        s->m = m;
+        s->g = g;
         s->device = device_ids ? device_ids[g] : g;
+        s->topo.numa_node = -1;
         rtlws_multi_partition(nframes, desc->k_avg, n_shards, g, &s->first_frame, &s->frames);
-        s->eng = rtlws_engine_create(s->device);
-        if (!s->eng) { rtlws_multi_close(m); return NULL; }
-        /* an empty shard still owns (1-byte) buffers: its launches are no-ops */
-        s->d_in = rtlws_dev_alloc(s->eng, (size_t)s->frames * m->frame_bytes);
-        s->d_out = rtlws_dev_alloc(s->eng, (size_t)(s->frames / desc->k_avg) * m->row_bytes);
-        s->ev0 = rtlws_event_create();
-        s->ev1 = rtlws_event_create();
-        if (!s->d_in || !s->d_out || !s->ev0 || !s->ev1 ||
-            (m->f64 ? rtlws_engine_prepare_f64(s->eng, desc->n_fft) : rtlws_engine_prepare(s->eng, desc->n_fft))) {
-            rtlws_multi_close(m);
-            return NULL;
-        }
+    }
+    for (g = 0; g < n_shards; g++) {
+        if (pthread_create(&m->sh[g].th, NULL, shard_main, &m->sh[g]) != 0) break;
+        m->sh[g].started = 1;
+        started++;
+    }
+    /* every shard pins itself and builds its own engine, buffers and tables, concurrently */
+    if (started < n_shards || post(m, started, CMD_INIT, 0, NULL, NULL) != 0) {
+        pthread_mutex_lock(&g_open_mu);
+        if (started < n_shards) snprintf(g_open_err, sizeof g_open_err, "rtlws_multi_open: could not create %d threads", n_shards);
+        else snprintf(g_open_err, sizeof g_open_err, "rtlws_multi_open: %s", m->err);
+        pthread_mutex_unlock(&g_open_mu);
+        m->n = started;                                  /* only these have a thread to tell */
+        rtlws_multi_close(m);
+        return NULL;
     }
     return m;
 }
@@ -106,160 +337,61 @@ long rtlws_multi_frames(const rtlws_multi* m) { return m ? m->nframes : 0; }
 size_t rtlws_multi_frame_bytes(const rtlws_multi* m) { return m ? m->frame_bytes : 0; }
 size_t rtlws_multi_row_bytes(const rtlws_multi* m) { return m ? m->row_bytes : 0; }
 
-/* ---- one thread per shard ------------------------------------------------ */
+const char* rtlws_multi_error(const rtlws_multi* m) { return m ? m->err : g_open_err; }
 
-enum { JOB_UPLOAD, JOB_RUN, JOB_DOWNLOAD };
-
-/* every shard's thread waits here until all of them exist: they start their work together
- * (or not at all, if a thread could not be created) */
-struct gate {
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    int state;                 /* 0 wait, 1 go, -1 give up */
-};
-
-struct job {
-    rtlws_multi* m;
-    int g, kind, launches, rc;
-    const unsigned char* host_in;
-    unsigned char* host_out;
-    struct gate* start;
-    double event_ms, wall_ms;
-};
-
-static int launch_once(rtlws_multi* m, struct shard* s)
+int rtlws_multi_shard_topology(const rtlws_multi* m, int g, rtlws_topo_info* out, int* cpus_pinned)
 {
-    return m->f64 ? rtlws_spectra_batch_f64(s->eng, &m->desc, s->d_in, s->frames, s->d_out, NULL)
-                  : rtlws_spectra_batch(s->eng, &m->desc, s->d_in, s->frames, s->d_out, NULL);
-}
-
-static void* job_main(void* arg)
-{
-    struct job* j = (struct job*)arg;
-    rtlws_multi* m = j->m;
-    struct shard* s = &m->sh[j->g];
-    const size_t in_off = (size_t)s->first_frame * m->frame_bytes;
-    const size_t out_off = (size_t)(s->first_frame / m->desc.k_avg) * m->row_bytes;
-    const size_t in_bytes = (size_t)s->frames * m->frame_bytes;
-    const size_t out_bytes = (size_t)(s->frames / m->desc.k_avg) * m->row_bytes;
-    int i;
-    double t0;
-    j->rc = 0;
-    pthread_mutex_lock(&j->start->mu);
-    while (j->start->state == 0) pthread_cond_wait(&j->start->cv, &j->start->mu);
-    i = j->start->state;
-    pthread_mutex_unlock(&j->start->mu);
-    if (i < 0) { j->rc = -3; return NULL; }
-    t0 = now_ms();
-    switch (j->kind) {
-    case JOB_UPLOAD:
-        if (in_bytes && (rtlws_copy_h2d(s->eng, s->d_in, j->host_in + in_off, in_bytes, NULL) ||
-                         rtlws_stream_sync(s->eng, NULL)))
-            j->rc = -3;
-        break;
-    case JOB_DOWNLOAD:
-        if (out_bytes && (rtlws_copy_d2h(s->eng, j->host_out + out_off, s->d_out, out_bytes, NULL) ||
-                          rtlws_stream_sync(s->eng, NULL)))
-            j->rc = -3;
-        break;
-    default:
-        if ((j->rc = rtlws_event_record(s->ev0, s->eng, NULL)) != 0) break;
-        for (i = 0; i < j->launches && j->rc == 0; i++) j->rc = launch_once(m, s);
-        if (j->rc == 0) j->rc = rtlws_event_record(s->ev1, s->eng, NULL);
-        if (j->rc == 0) j->rc = rtlws_stream_sync(s->eng, NULL);
-        if (j->rc == 0) j->event_ms = (double)rtlws_event_elapsed_ms(s->ev0, s->ev1);
-        break;
-    }
-    j->wall_ms = now_ms() - t0;
-    return NULL;
-}
-
-static int run_jobs(rtlws_multi* m, int kind, int launches, const void* host_in, void* host_out,
-                    rtlws_multi_shard_stats* stats, double* wall_ms_max)
-{
-    struct job* jobs;
-    pthread_t* th;
-    struct gate start;
-    int g, rc = 0, started = 0;
-    double worst = 0.0;
-    if (!m) return -1;
-    jobs = (struct job*)calloc((size_t)m->n, sizeof(*jobs));
-    th = (pthread_t*)calloc((size_t)m->n, sizeof(*th));
-    if (!jobs || !th) { free(jobs); free(th); return -3; }
-    pthread_mutex_init(&start.mu, NULL);
-    pthread_cond_init(&start.cv, NULL);
-    start.state = 0;
-    for (g = 0; g < m->n; g++) {
-        jobs[g].m = m;
-        jobs[g].g = g;
-        jobs[g].kind = kind;
-        jobs[g].launches = launches;
-        jobs[g].host_in = (const unsigned char*)host_in;
-        jobs[g].host_out = (unsigned char*)host_out;
-        jobs[g].start = &start;
-        if (pthread_create(&th[g], NULL, job_main, &jobs[g]) != 0) break;
-        started++;
-    }
-    pthread_mutex_lock(&start.mu);
-    start.state = (started == m->n) ? 1 : -1;     /* all shards, or none */
-    pthread_cond_broadcast(&start.cv);
-    pthread_mutex_unlock(&start.mu);
-    for (g = 0; g < started; g++) pthread_join(th[g], NULL);
-    pthread_mutex_destroy(&start.mu);
-    pthread_cond_destroy(&start.cv);
-    if (started < m->n) rc = -3;
-    for (g = 0; g < m->n; g++) {
-        if (jobs[g].rc && !rc) rc = jobs[g].rc;
-        if (jobs[g].wall_ms > worst) worst = jobs[g].wall_ms;
-        if (stats) {
-            stats[g].device = m->sh[g].device;
-            stats[g].first_frame = m->sh[g].first_frame;
-            stats[g].frames = m->sh[g].frames;
-            stats[g].launches = launches;
-            stats[g].event_ms = jobs[g].event_ms;
-            stats[g].wall_ms = jobs[g].wall_ms;
-            stats[g].rc = jobs[g].rc;
-        }
-    }
-    if (wall_ms_max) *wall_ms_max = worst;
-    free(jobs);
-    free(th);
-    return rc;
+    if (!m || g < 0 || g >= m->n) return -1;
+    if (out) *out = m->sh[g].topo;
+    if (cpus_pinned) *cpus_pinned = m->sh[g].cpus_pinned;
+    return 0;
 }
 
 int rtlws_multi_upload(rtlws_multi* m, const void* host_frames)
 {
     if (!m || (!host_frames && m->nframes)) return -1;
-    return run_jobs(m, JOB_UPLOAD, 0, host_frames, NULL, NULL, NULL);
+    return post(m, m->n, CMD_UPLOAD, 0, host_frames, NULL);
 }
 
 int rtlws_multi_run(rtlws_multi* m, int launches, rtlws_multi_shard_stats* stats, double* wall_ms_max)
 {
+    int g, rc;
+    double worst = 0.0;
     if (!m || launches < 0) return -1;
-    return run_jobs(m, JOB_RUN, launches, NULL, NULL, stats, wall_ms_max);
+    rc = post(m, m->n, CMD_RUN, launches, NULL, NULL);
+    for (g = 0; g < m->n; g++) {
+        const struct shard* s = &m->sh[g];
+        if (s->wall_ms > worst) worst = s->wall_ms;
+        if (stats) {
+            stats[g].device = s->device;
+            stats[g].first_frame = s->first_frame;
+            stats[g].frames = s->frames;
+            stats[g].launches = launches;
+            stats[g].event_ms = s->event_ms;
+            stats[g].wall_ms = s->wall_ms;
+            stats[g].rc = s->rc;
+        }
+    }
+    if (wall_ms_max) *wall_ms_max = worst;
+    return rc;
 }
 
 int rtlws_multi_download(rtlws_multi* m, void* host_rows)
 {
     if (!m || (!host_rows && m->nframes)) return -1;
-    return run_jobs(m, JOB_DOWNLOAD, 0, NULL, host_rows, NULL, NULL);
+    return post(m, m->n, CMD_DOWNLOAD, 0, NULL, host_rows);
 }
 
 void rtlws_multi_close(rtlws_multi* m)
 {
     int g;
     if (!m) return;
-    for (g = 0; g < m->n; g++) {
-        struct shard* s = &m->sh[g];
-        if (s->eng) {
-            rtlws_stream_sync(s->eng, NULL);
-            rtlws_dev_free(s->eng, s->d_in);
-            rtlws_dev_free(s->eng, s->d_out);
-        }
-        rtlws_event_destroy(s->ev0);
-        rtlws_event_destroy(s->ev1);
-        rtlws_engine_destroy(s->eng);
-    }
+    post(m, m->n, CMD_EXIT, 0, NULL, NULL);            /* each thread frees what it created, then leaves */
+    for (g = 0; g < m->n; g++)
+        if (m->sh[g].started) pthread_join(m->sh[g].th, NULL);
+    pthread_mutex_destroy(&m->mu);
+    pthread_cond_destroy(&m->cv_cmd);
+    pthread_cond_destroy(&m->cv_done);
     free(m->sh);
     free(m);
 }

@@ -13,7 +13,12 @@
  *                          roofline with Q = 1, 0.71-0.72 with Q = 2 or 3 (profiles/r04_shards_one_device.txt)
  *   --shards-on-device0 S  rehearsal: S shards, all on device 0 (the S-shard code path on one GPU;
  *                          the line says so and is not a scaling measurement)
- *   --plan-only            print the frame ranges for --devices D and exit: no GPU is touched
+ *   --plan-only            print the plan for --devices D and exit: frame range, PCI bus id, NUMA node and cpuset
+ *                          of every device.  No GPU is touched when --bus-ids names the devices' bus ids (planning
+ *                          for another host; tests); without it the HIP runtime is asked, and a host without a
+ *                          device gets the ranges alone
+ *   --bus-ids a,b,...      (with --plan-only) bus id of device 0, 1, ...: "0000:05:00.0,0000:15:00.0"
+ *   --sysfs-root DIR       (with --plan-only) read NUMA nodes and cpusets under DIR instead of /sys
  */
 #include <math.h>
 #include <stdio.h>
@@ -45,6 +50,8 @@ int main(int argc, char** argv)
     int output = RTLWS_OUT_POWER_SUM, window = RTLWS_WIN_RECT, flags = 0, f64 = 0, rc;
     const char* precision = "f32";
     const char* output_name = "f32";
+    const char* bus_ids = NULL;
+    const char* sysfs_root = NULL;
     rtlws_spectra_desc d;
     rtlws_multi* m;
     rtlws_multi_shard_stats* st;
@@ -62,6 +69,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--shards-on-device0") && i + 1 < argc) rehearsal = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--shards-per-device") && i + 1 < argc) per_dev = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--plan-only")) plan_only = 1;
+        else if (!strcmp(argv[i], "--bus-ids") && i + 1 < argc) bus_ids = argv[++i];
+        else if (!strcmp(argv[i], "--sysfs-root") && i + 1 < argc) sysfs_root = argv[++i];
         else if (!strcmp(argv[i], "--window") && i + 1 < argc) window = !strcmp(argv[++i], "hann") ? RTLWS_WIN_HANN : RTLWS_WIN_RECT;
         else if (!strcmp(argv[i], "--precision") && i + 1 < argc) {
             precision = argv[++i];
@@ -85,8 +94,22 @@ int main(int argc, char** argv)
                frames, frames - frames % k, k, devices);
         for (g = 0; g < devices; g++) {
             long first, count;
+            rtlws_topo_info t;
+            char one[32];
+            const char* bus = NULL;
             rtlws_multi_partition(frames, k, devices, g, &first, &count);
-            printf("%s{\"device\": %d, \"first_frame\": %ld, \"frames\": %ld}", g ? ", " : "", g, first, count);
+            if (bus_ids) {                 /* the g-th comma-separated entry */
+                const char* p = bus_ids;
+                int skip = g;
+                size_t n;
+                while (skip > 0 && (p = strchr(p, ',')) != NULL) { ++p; --skip; }
+                n = p ? strcspn(p, ",") : 0;
+                if (p && n > 0 && n < sizeof one) { memcpy(one, p, n); one[n] = 0; bus = one; }
+                else bus = "";
+            }
+            if (rtlws_topo_describe(bus ? -1 : g, bus, sysfs_root, &t) != 0) memset(&t, 0, sizeof t), t.numa_node = -1;
+            printf("%s{\"device\": %d, \"first_frame\": %ld, \"frames\": %ld, \"bus_id\": \"%s\", \"numa_node\": %d, "
+                   "\"cpus\": %d, \"cpulist\": \"%s\"}", g ? ", " : "", g, first, count, t.bus_id, t.numa_node, t.ncpus, t.cpulist);
         }
         printf("]}\n");
         return 0;
@@ -107,7 +130,7 @@ int main(int argc, char** argv)
         for (g = 0; g < n; g++) ids[g] = g / per_dev;     /* contiguous frame ranges stay on one device */
     }
     m = rtlws_multi_open(n, ids, &d, frames, f64);
-    if (!m) { fprintf(stderr, "rtlws_multi_open failed: %s\n", rtlws_last_error()); return 3; }
+    if (!m) { fprintf(stderr, "%s\n", rtlws_multi_error(NULL)); return 3; }
     {
         const size_t fb = rtlws_multi_frame_bytes(m);
         host = (unsigned char*)malloc((size_t)frames * fb + 1);
@@ -118,7 +141,7 @@ int main(int argc, char** argv)
     rc = rtlws_multi_upload(m, host);
     if (!rc && warmup) rc = rtlws_multi_run(m, warmup, NULL, NULL);     /* clock governor + code objects */
     if (!rc) rc = rtlws_multi_run(m, launches, st, &wall_ms);
-    if (rc) { fprintf(stderr, "run failed (%d): %s\n", rc, rtlws_last_error()); return 3; }
+    if (rc) { fprintf(stderr, "run failed (%d): %s\n", rc, rtlws_multi_error(m)); return 3; }
     frames = rtlws_multi_frames(m);                 /* whole K-groups */
     total = (double)frames * launches / (wall_ms * 1e-3);
     bytes_per_frame = (double)rtlws_multi_frame_bytes(m) + (double)rtlws_multi_row_bytes(m) / k;
@@ -130,10 +153,15 @@ int main(int argc, char** argv)
            launches, warmup, wall_ms, total, bytes_per_frame);
     for (g = 0; g < n; g++) {
         const double ev_s = st[g].event_ms * 1e-3 / launches;
+        rtlws_topo_info t;
+        int pinned = 0;
+        rtlws_multi_shard_topology(m, g, &t, &pinned);
         printf("%s{\"shard\": %d, \"device\": %d, \"first_frame\": %ld, \"frames\": %ld, \"event_ms_per_launch\": %.5f, "
-               "\"wall_ms\": %.4f, \"spectra_per_s\": %.1f, \"hbm_gbs\": %.1f}", g ? ", " : "", g, st[g].device,
+               "\"wall_ms\": %.4f, \"spectra_per_s\": %.1f, \"hbm_gbs\": %.1f, \"bus_id\": \"%s\", \"numa_node\": %d, "
+               "\"cpus_pinned\": %d}", g ? ", " : "", g, st[g].device,
                st[g].first_frame, st[g].frames, st[g].event_ms / launches, st[g].wall_ms,
-               ev_s > 0 ? (double)st[g].frames / ev_s : 0.0, ev_s > 0 ? bytes_per_frame * (double)st[g].frames / ev_s / 1e9 : 0.0);
+               ev_s > 0 ? (double)st[g].frames / ev_s : 0.0, ev_s > 0 ? bytes_per_frame * (double)st[g].frames / ev_s / 1e9 : 0.0,
+               t.bus_id, t.numa_node, pinned);
     }
     printf("]}\n");
     rtlws_multi_close(m);

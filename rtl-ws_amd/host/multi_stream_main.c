@@ -13,7 +13,9 @@
  *   --chunk-buffers M  M sensor buffers per chunk (unpaced throughput runs)
  *   --precision        arithmetic of the streams: the f32 fused kernel (default), the reference's f64
  *                      (rows of doubles), or f64 arithmetic with f32 rows (rtlws_stream.h, desc.flags)
- *   --plan-only        print the stream -> device plan for D devices and exit (no GPU needed)
+ *   --plan-only        print the stream -> device plan for D devices and exit: device, PCI bus id, NUMA node and
+ *                      cpuset per stream.  --bus-ids a,b,... names the devices' bus ids (no GPU is asked then),
+ *                      --sysfs-root DIR reads the NUMA information under DIR instead of /sys
  */
 #include <math.h>
 #include <pthread.h>
@@ -36,6 +38,8 @@ struct producer {
     double elapsed_s;
     volatile double checksum;
     long rows_seen;
+    rtlws_topo_info topo;
+    int cpus_pinned;
 };
 
 static void on_rows(const void* rows, long nrows, long first_frame, double latency_ms, void* user)
@@ -64,6 +68,13 @@ static void* producer_main(void* arg)
     unsigned x = 2463534242u + 977u * (unsigned)p->id;
     double t0, next;
     long i;
+    /* this thread feeds device p->device for the rest of its life: stay on that device's NUMA node, so the
+     * buffer below is first touched there and every push's memcpy into a ring slot is node-local */
+    {
+        rtlws_topo_info t;
+        rtlws_topo_describe(p->device, NULL, NULL, &t);
+        (void)rtlws_topo_pin_thread(&t);
+    }
     for (i = 0; i < (long)BUF_SAMPLES * p->chunk_buffers; i++) {      /* tone + noise, different per stream */
         double ph = 2.0 * 3.14159265358979 * (0.05 + 0.1 * p->id) * (double)i;
         double re, im;
@@ -76,6 +87,7 @@ static void* producer_main(void* arg)
     }
     p->st = rtlws_stream_open_q(p->device, &p->desc, frames, 4, p->queues, on_rows, p);
     if (!p->st) { fprintf(stderr, "stream %d: open failed: %s\n", p->id, rtlws_last_error()); free(buf); return NULL; }
+    rtlws_stream_topology(p->st, &p->topo, &p->cpus_pinned);
     t0 = now_s();
     next = t0;
     while (now_s() - t0 < p->seconds) {
@@ -104,6 +116,8 @@ int main(int argc, char** argv)
     int chunk_buffers = 1, plan_only = 0, devices_override = 0, queues_override = 0;
     const char* output_name = "f32";
     const char* precision = "f32";
+    const char* bus_ids = NULL;
+    const char* sysfs_root = NULL;
     int flags = 0;
     double seconds = 3.0, rate = 2400000.0;
     struct producer* ps;
@@ -119,6 +133,8 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--unpaced")) unpaced = 1;
         else if (!strcmp(argv[i], "--chunk-buffers") && i + 1 < argc) chunk_buffers = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--plan-only")) plan_only = 1;
+        else if (!strcmp(argv[i], "--bus-ids") && i + 1 < argc) bus_ids = argv[++i];
+        else if (!strcmp(argv[i], "--sysfs-root") && i + 1 < argc) sysfs_root = argv[++i];
         else if (!strcmp(argv[i], "--queues") && i + 1 < argc) queues_override = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices_override = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--precision") && i + 1 < argc) {
@@ -141,6 +157,24 @@ int main(int argc, char** argv)
         if (devices_override < 1) { fprintf(stderr, "--plan-only needs --devices D\n"); return 2; }
         printf("{\"streams\": %d, \"devices\": %d, \"plan_only\": true, \"stream_devices\": [", streams, devices_override);
         for (i = 0; i < streams; i++) printf("%s%d", i ? ", " : "", rtlws_stream_device_for(i, devices_override));
+        printf("], \"device_topology\": [");
+        for (i = 0; i < devices_override; i++) {
+            rtlws_topo_info t;
+            char one[32];
+            const char* bus = NULL;
+            if (bus_ids) {                 /* the i-th comma-separated entry */
+                const char* p = bus_ids;
+                int skip = i;
+                size_t n;
+                while (skip > 0 && (p = strchr(p, ',')) != NULL) { ++p; --skip; }
+                n = p ? strcspn(p, ",") : 0;
+                if (p && n > 0 && n < sizeof one) { memcpy(one, p, n); one[n] = 0; bus = one; }
+                else bus = "";
+            }
+            if (rtlws_topo_describe(bus ? -1 : i, bus, sysfs_root, &t) != 0) { memset(&t, 0, sizeof t); t.numa_node = -1; }
+            printf("%s{\"device\": %d, \"bus_id\": \"%s\", \"numa_node\": %d, \"cpus\": %d, \"cpulist\": \"%s\"}",
+                   i ? ", " : "", i, t.bus_id, t.numa_node, t.ncpus, t.cpulist);
+        }
         printf("]}\n");
         return 0;
     }
@@ -188,10 +222,11 @@ int main(int argc, char** argv)
            total_rate / streams, frames, drops, failed, lat_avg, lat_max);
     for (i = 0; i < streams; i++)
         printf("%s{\"stream\": %d, \"device\": %d, \"queues\": %d, \"spectra_per_s\": %.1f, \"chunks_dropped\": %ld, \"chunks_failed\": %ld, "
-               "\"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f}", i ? ", " : "", i, ps[i].device, ps[i].queues,
+               "\"latency_ms_avg\": %.3f, \"latency_ms_max\": %.3f, \"bus_id\": \"%s\", \"numa_node\": %d, \"cpus_pinned\": %d}",
+               i ? ", " : "", i, ps[i].device, ps[i].queues,
                ps[i].elapsed_s > 0 ? (double)ps[i].stats.frames_done / ps[i].elapsed_s : 0.0,
                ps[i].stats.chunks_dropped, ps[i].stats.chunks_failed, ps[i].stats.latency_ms_avg,
-               ps[i].stats.latency_ms_max);
+               ps[i].stats.latency_ms_max, ps[i].topo.bus_id, ps[i].topo.numa_node, ps[i].cpus_pinned);
     printf("]}\n");
     free(ps);
     free(th);

@@ -21,6 +21,7 @@
  * so the count is the caller's: rtlws_stream_open() takes RTLWS_STREAM_QUEUES (default 1),
  * rtlws_stream_open_q() an argument -- the configs[4] driver gives a device's only sensor
  * four queues and sensors that share a device one each. */
+#define _GNU_SOURCE
 #include "rtlws_stream.h"
 
 #include <pthread.h>
@@ -28,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+
+#include "topology.h"
 
 enum { SLOT_FREE = 0, SLOT_IN_FLIGHT = 1 };
 
@@ -65,6 +68,8 @@ struct rtlws_stream {
     int worker_ready;                /* the worker thread has made its first HIP call */
     rtlws_stream_stats st;
     double lat_sum;
+    rtlws_topo_info topo;            /* the device's NUMA node and its CPUs */
+    int cpus_pinned;                 /* CPUs the worker thread (and the slots' first touch) is pinned to */
 };
 
 int rtlws_stream_device_for(int stream_index, int device_count)
@@ -169,16 +174,40 @@ rtlws_stream* rtlws_stream_open(int device, const rtlws_spectra_desc* desc, long
     return rtlws_stream_open_q(device, desc, frames_per_chunk, ring_slots, queues, cb, user);
 }
 
+static rtlws_stream* open_pinned(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                 int ring_slots, int queues, rtlws_stream_callback cb, void* user,
+                                 const rtlws_topo_info* topo, int cpus_pinned);
+
 rtlws_stream* rtlws_stream_open_q(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
                                   int ring_slots, int queues, rtlws_stream_callback cb, void* user)
 {
     rtlws_stream* s;
-    int i;
+    rtlws_topo_info topo;
+    cpu_set_t saved;
+    int have_saved = 0, pinned;
     if (!desc || rtlws_spectra_kernel_kind(desc) == 0 || frames_per_chunk <= 0 ||
         frames_per_chunk % desc->k_avg || ring_slots < 2 || queues < 1 || queues > 8 || queues > ring_slots)
         return NULL;
+    /* everything below -- the pinned slots' allocation and first touch, the warm start, the worker thread's
+     * creation (a new thread inherits its creator's mask) -- happens next to the device; the caller gets its
+     * own mask back on every way out */
+    rtlws_topo_describe(device, NULL, NULL, &topo);
+    pinned = rtlws_topo_pin_save(&topo, &saved, &have_saved);
+    s = open_pinned(device, desc, frames_per_chunk, ring_slots, queues, cb, user, &topo, pinned > 0 ? pinned : 0);
+    rtlws_topo_restore(&saved, have_saved);
+    return s;
+}
+
+static rtlws_stream* open_pinned(int device, const rtlws_spectra_desc* desc, long frames_per_chunk,
+                                 int ring_slots, int queues, rtlws_stream_callback cb, void* user,
+                                 const rtlws_topo_info* topo, int cpus_pinned)
+{
+    rtlws_stream* s;
+    int i;
     s = (rtlws_stream*)calloc(1, sizeof(*s));
     if (!s) return NULL;
+    s->topo = *topo;
+    s->cpus_pinned = cpus_pinned;
     s->eng = rtlws_engine_create(device);
     if (!s->eng) { free(s); return NULL; }
     s->desc = *desc;
@@ -317,6 +346,14 @@ void rtlws_stream_get_stats(rtlws_stream* s, rtlws_stream_stats* out)
         out->latency_ms_avg = delivered ? s->lat_sum / (double)delivered : 0.0;
     }
     pthread_mutex_unlock(&s->mu);
+}
+
+int rtlws_stream_topology(const rtlws_stream* s, rtlws_topo_info* out, int* cpus_pinned)
+{
+    if (!s) return -1;
+    if (out) *out = s->topo;
+    if (cpus_pinned) *cpus_pinned = s->cpus_pinned;
+    return 0;
 }
 
 void rtlws_stream_close(rtlws_stream* s)

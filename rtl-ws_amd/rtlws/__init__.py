@@ -54,13 +54,19 @@ class CmplxS32(C.Structure):
     _fields_ = [("re", C.c_int32), ("im", C.c_int32)]
 
 
+class TopoInfo(C.Structure):
+    """rtlws_topo_info (include/rtlws_topo.h)"""
+    _fields_ = [("device", C.c_int), ("bus_id", C.c_char * 32), ("numa_node", C.c_int), ("ncpus", C.c_int),
+                ("cpulist", C.c_char * 512)]
+
+
 class CicDelayLine(C.Structure):
     _fields_ = [("integrator_prev_out", CmplxS32), ("comb_prev_in", CmplxS32)]
 
 
 # every symbol include/*.h declares, by library (tests check the exports)
 HIP_SYMBOLS = [
-    "rtlws_device_count", "rtlws_engine_create", "rtlws_engine_destroy", "rtlws_engine_device",
+    "rtlws_device_count", "rtlws_device_pci_bus_id", "rtlws_engine_create", "rtlws_engine_destroy", "rtlws_engine_device",
     "rtlws_engine_prepare", "rtlws_engine_prepare_f64", "rtlws_engine_set_option", "rtlws_engine_get_option",
     "rtlws_last_error", "rtlws_dev_alloc", "rtlws_dev_free", "rtlws_pinned_alloc",
     "rtlws_pinned_free", "rtlws_copy_h2d", "rtlws_copy_d2h", "rtlws_memset_dev",
@@ -76,7 +82,7 @@ HIP_SYMBOLS = [
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
 STREAM_SYMBOLS = ["rtlws_stream_open", "rtlws_stream_open_q", "rtlws_stream_push", "rtlws_stream_flush",
-                  "rtlws_stream_get_stats", "rtlws_stream_close", "rtlws_stream_device_for"]
+                  "rtlws_stream_get_stats", "rtlws_stream_close", "rtlws_stream_device_for", "rtlws_stream_topology"]
 AMD_SYMBOLS = [
     "spectrum_alloc", "spectrum_add_cmplx_u8", "spectrum_add_cmplx_s32", "spectrum_add_real_f32",
     "spectrum_free", "cic_decimate", "halfband_decimate", "rf_decimator_alloc",
@@ -87,7 +93,9 @@ AMD_SYMBOLS = [
 # include/rtlws_multi.h: one device-resident batch sharded over the devices of a node (librtlws_amd.so)
 MULTI_SYMBOLS = ["rtlws_multi_partition", "rtlws_multi_open", "rtlws_multi_shards", "rtlws_multi_frames",
                  "rtlws_multi_frame_bytes", "rtlws_multi_row_bytes", "rtlws_multi_upload", "rtlws_multi_run",
-                 "rtlws_multi_download", "rtlws_multi_close"]
+                 "rtlws_multi_download", "rtlws_multi_close", "rtlws_multi_error", "rtlws_multi_shard_topology"]
+# include/rtlws_topo.h (librtlws_amd.so)
+TOPO_SYMBOLS = ["rtlws_topo_describe", "rtlws_topo_parse_cpulist", "rtlws_topo_pin_thread"]
 
 # include/rtlws_host.h: sticky failure record of the void entry points (librtlws_amd.so)
 HOST_SYMBOLS = ["rtlws_host_error", "rtlws_host_error_count", "rtlws_host_error_clear"]
@@ -222,6 +230,12 @@ def amd_lib():
         L.rtlws_multi_run.argtypes = [vp, i, vp, C.POINTER(C.c_double)]
         L.rtlws_multi_download.argtypes = [vp, vp]
         L.rtlws_multi_close.argtypes = [vp]
+        L.rtlws_multi_error.argtypes = [vp]
+        L.rtlws_multi_error.restype = C.c_char_p
+        L.rtlws_multi_shard_topology.argtypes = [vp, i, C.POINTER(TopoInfo), C.POINTER(i)]
+        L.rtlws_topo_describe.argtypes = [i, C.c_char_p, C.c_char_p, C.POINTER(TopoInfo)]
+        L.rtlws_topo_parse_cpulist.argtypes = [C.c_char_p, vp, i]
+        L.rtlws_topo_pin_thread.argtypes = [C.POINTER(TopoInfo)]
         L.rtlws_host_error.restype = C.c_char_p
         L.rtlws_host_error_count.restype = C.c_long
         L.rtlws_host_error_clear.restype = None
@@ -550,7 +564,7 @@ class MultiBatch:
         self.desc, self.f64 = desc, f64
         self.h = L.rtlws_multi_open(n, ids, C.byref(desc), int(nframes), 1 if f64 else 0)
         if not self.h:
-            raise RuntimeError("rtlws_multi_open failed: %s" % last_error())
+            raise RuntimeError("rtlws_multi_open failed: %s" % (L.rtlws_multi_error(None).decode() or last_error()))
         self.shards = L.rtlws_multi_shards(self.h)
         self.frames = L.rtlws_multi_frames(self.h)
 
@@ -559,14 +573,14 @@ class MultiBatch:
         assert frames.nbytes >= self.frames * amd_lib().rtlws_multi_frame_bytes(self.h)
         rc = amd_lib().rtlws_multi_upload(self.h, _p(frames))
         if rc:
-            raise RuntimeError("rtlws_multi_upload rc=%d: %s" % (rc, last_error()))
+            raise RuntimeError("rtlws_multi_upload rc=%d: %s" % (rc, self.error()))
 
     def run(self, launches=1):
         st = (MultiShardStats * self.shards)()
         wall = C.c_double(0.0)
         rc = amd_lib().rtlws_multi_run(self.h, int(launches), st, C.byref(wall))
         if rc:
-            raise RuntimeError("rtlws_multi_run rc=%d: %s" % (rc, last_error()))
+            raise RuntimeError("rtlws_multi_run rc=%d: %s" % (rc, self.error()))
         return list(st), wall.value
 
     def download(self):
@@ -576,8 +590,19 @@ class MultiBatch:
         out = np.empty((rows, self.desc.n_fft), dtype=dt)
         rc = amd_lib().rtlws_multi_download(self.h, _p(out))
         if rc:
-            raise RuntimeError("rtlws_multi_download rc=%d: %s" % (rc, last_error()))
+            raise RuntimeError("rtlws_multi_download rc=%d: %s" % (rc, self.error()))
         return out
+
+    def error(self):
+        """why the last upload / run / download failed (the failing call ran on a shard's own thread)"""
+        return amd_lib().rtlws_multi_error(self.h).decode()
+
+    def topology(self, g):
+        """(TopoInfo, cpus the shard's thread pinned itself to) of shard g"""
+        t, n = TopoInfo(), C.c_int(0)
+        if amd_lib().rtlws_multi_shard_topology(self.h, int(g), C.byref(t), C.byref(n)) != 0:
+            raise IndexError(g)
+        return t, n.value
 
     def close(self):
         if self.h:
@@ -589,6 +614,14 @@ class MultiBatch:
             self.close()
         except Exception:
             pass
+
+
+def topo_describe(device=-1, bus_id=None, sysfs_root=None):
+    """rtlws_topo_describe: TopoInfo of a device (bus_id given: no GPU is asked).  None on bad arguments."""
+    t = TopoInfo()
+    rc = amd_lib().rtlws_topo_describe(int(device), None if bus_id is None else bus_id.encode(),
+                                       None if sysfs_root is None else str(sysfs_root).encode(), C.byref(t))
+    return t if rc == 0 else None
 
 
 # ---- boundary #2 (librtlws_cbb.so over the synthetic sensor) ------------------

@@ -53,8 +53,12 @@ static int g_iq_next = 0;
 static unsigned char* g_h_payload = NULL;
 static int g_pub_count = 0;             /* frames behind g_d_pub */
 static uint64_t g_last_est_ms = 0;
-static volatile int g_new_spectrum = 0;
+/* written on the sensor thread, read on the server thread, without g_mu: the reference keeps these in a
+ * `volatile int` (src/cbb_main.c:21,28), which is a data race in C11; here they are atomics */
+static int g_new_spectrum = 0;
 static uint64_t g_samples_seen = 0;
+#define FLAG_SET(v)   __atomic_store_n(&g_new_spectrum, (v), __ATOMIC_RELEASE)
+#define FLAG_GET()    __atomic_load_n(&g_new_spectrum, __ATOMIC_ACQUIRE)
 static int g_max_blocks = FFT_AVERAGE;  /* RTLWS_CBB_ALL_FRAMES=1|2: every frame of the buffer */
 #define MAX_BLOCKS_ALL 1024             /* device staging bound for those modes (2 MiB of IQ) */
 /* RTLWS_CBB_ALL_FRAMES=2 ("Welch averaging over the whole 250 ms"):
@@ -78,7 +82,7 @@ static uint64_t now_ms(void)
 static void count_samples(const cmplx_u8* signal, int len)
 {
     (void)signal;
-    g_samples_seen += (uint64_t)(len > 0 ? len : 0);
+    __atomic_fetch_add(&g_samples_seen, (uint64_t)(len > 0 ? len : 0), __ATOMIC_RELAXED);
 }
 
 /* callback #2 (reference src/cbb_main.c:35-38) */
@@ -143,12 +147,12 @@ static void estimate_spectrum(const cmplx_u8* signal, int len)
             rtlws_memset_dev(g_eng, g_d_acc, 0, FFT_POINTS * sizeof(double), NULL);
         }
         g_last_est_ms = now_ms();
-        g_new_spectrum = 1;
+        FLAG_SET(1);
         pthread_mutex_unlock(&g_mu);
         return;
     }
     g_last_est_ms = now_ms();                                     /* :61 */
-    g_new_spectrum = 1;                                           /* :62 */
+    FLAG_SET(1);                                                  /* :62 */
     {   /* publish: swap instead of the reference's 8 KiB memcpy (:64-69) */
         double* t = g_d_pub;
         g_d_pub = g_d_work;
@@ -233,8 +237,8 @@ void cbb_init(int decimated_bw_target_hz)
     }
     g_pub_count = 0;
     g_last_est_ms = 0;
-    g_new_spectrum = 0;
-    g_samples_seen = 0;
+    FLAG_SET(0);
+    __atomic_store_n(&g_samples_seen, (uint64_t)0, __ATOMIC_RELAXED);
 
     signal_source_start(g_dev);                                   /* :85 */
     signal_source_add_callback(count_samples);                    /* :86 */
@@ -246,7 +250,7 @@ struct rtl_dev* cbb_get_rtl_dev(void) { return g_dev; }          /* :91-94 */
 
 struct rf_decimator* cbb_rf_decimator(void) { return g_decim; }   /* :96-99 */
 
-int cbb_new_spectrum_available(void) { return g_new_spectrum; }   /* :101-104 */
+int cbb_new_spectrum_available(void) { return FLAG_GET(); }       /* :101-104 */
 
 int cbb_get_spectrum_payload(char* buf, int buf_len, int spectrum_gain_db)
 {
@@ -264,7 +268,7 @@ int cbb_get_spectrum_payload(char* buf, int buf_len, int spectrum_gain_db)
         }
     }
     pthread_mutex_unlock(&g_mu);
-    g_new_spectrum = 0;                                           /* :132 */
+    FLAG_SET(0);                                                  /* :132 */
     return len;
 }
 
@@ -293,4 +297,4 @@ int rtlws_cbb_published_frames(void)
 }
 
 /* test/diagnostic hook: complex samples the callbacks have seen so far */
-uint64_t rtlws_cbb_samples_seen(void) { return g_samples_seen; }
+uint64_t rtlws_cbb_samples_seen(void) { return __atomic_load_n(&g_samples_seen, __ATOMIC_RELAXED); }

@@ -25,7 +25,7 @@ struct rtl_dev {
     uint32_t f;
     uint32_t fs;
     double gain;
-    volatile int cancel;
+    int cancel;                    /* set by rtl_cancel on another thread: accessed atomically */
 };
 
 int rtl_init(struct rtl_dev** dev, int dev_index)
@@ -111,7 +111,7 @@ int rtl_read_async(struct rtl_dev* dev, void (*callback)(unsigned char*, uint32_
     if (!buf) { free(data); return -1; }
     clock_gettime(CLOCK_MONOTONIC, &next);
 
-    while (!dev->cancel) {
+    while (!__atomic_load_n(&dev->cancel, __ATOMIC_ACQUIRE)) {
         if (maxbufs > 0 && delivered >= maxbufs) {       /* drained: idle until cancelled */
             struct timespec nap = {0, 2000000};
             nanosleep(&nap, NULL);
@@ -133,7 +133,7 @@ int rtl_read_async(struct rtl_dev* dev, void (*callback)(unsigned char*, uint32_
             next.tv_nsec %= 1000000000L;
             clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &next, NULL);
         }
-        if (dev->cancel) break;
+        if (__atomic_load_n(&dev->cancel, __ATOMIC_ACQUIRE)) break;
         callback(buf, (uint32_t)buflen, user);
         delivered++;
     }
@@ -142,6 +142,6 @@ int rtl_read_async(struct rtl_dev* dev, void (*callback)(unsigned char*, uint32_
     return 0;
 }
 
-void rtl_cancel(struct rtl_dev* dev) { dev->cancel = 1; }
+void rtl_cancel(struct rtl_dev* dev) { __atomic_store_n(&dev->cancel, 1, __ATOMIC_RELEASE); }
 
 void rtl_close(struct rtl_dev* dev) { free(dev); }

@@ -15,7 +15,7 @@ static pthread_mutex_t g_cb_mu = PTHREAD_MUTEX_INITIALIZER;
 static signal_source_callback g_cbs[MAX_CALLBACKS];
 static int g_ncbs = 0;
 static struct rtl_dev* g_sensor = NULL;
-static volatile int g_running = 0;
+static int g_running = 0;           /* start / stop come from one thread; the worker reads it once, after its creation */
 
 static void on_buffer(unsigned char* buf, uint32_t len_bytes, void* user)
 {

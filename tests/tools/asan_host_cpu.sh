@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../.."
 OUT=/tmp/rtlws_asan_host
 mkdir -p $OUT
-SRCS="host_ctx spectrum_gpu rf_decimator_gpu stream_gpu audio_gpu multi_batch"
+SRCS="host_ctx spectrum_gpu rf_decimator_gpu stream_gpu audio_gpu multi_batch topology"
 OBJS=""
 for s in $SRCS; do
   gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -Wall -Wextra -std=gnu99 \
@@ -18,5 +18,5 @@ gcc -shared -fPIC -fsanitize=address,undefined -o $OUT/librtlws_amd.so $OBJS -Lr
     -Wl,-rpath,$PWD/rtl-ws_amd/lib -lpthread -lm
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
 ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1 RTLWS_AMD_LIB=$OUT/librtlws_amd.so \
-    python -m pytest tests/test_abi_cpu.py tests/test_multi_batch_cpu.py -q -x \
+    python -m pytest tests/test_abi_cpu.py tests/test_multi_batch_cpu.py tests/test_topo_cpu.py -q -x \
     -k "not call_graph and not launch_path and not cbb_init and not exported"

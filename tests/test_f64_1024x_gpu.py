@@ -85,3 +85,35 @@ def test_x1024_full_size_config2(engine, oracle):
     ref = oracle.batch_spectra_u8(iq, 1024, nthreads=16)
     worst = max(float(rel_err(got[lo:lo + 8192], ref[lo:lo + 8192], EPS_STRICT).max()) for lo in range(0, 65536, 8192))
     assert worst <= STRICT_F64, worst
+
+
+@pytest.mark.parametrize("rows,k_avg", [(1, 1), (7, 1), (255, 1), (257, 3), (2049, 1), (9001, 2)])
+@pytest.mark.parametrize("rows_f32", [False, True])
+def test_x1024_eight_wavefront_workgroups(engine, oracle, rows, k_avg, rows_f32):
+    """The WAVES = 8 form (one workgroup per CU, its wavefronts take the workgroup's rows one at a time from an
+    LDS counter; batches of >= 32 rows per CU take it by themselves) forced on batches of every shape -- fewer rows
+    than workgroups, than wavefronts, ragged -- against the oracle and, bit for bit, against the one-wavefront
+    workgroups: only the row-to-wavefront map differs (src/spectrum.c:15-35,47-63, K loop of src/cbb_main.c:50-59)."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(rows * k_avg, 1024, seed=900 + rows)
+    iq[0] = 128
+    with engine.option("f64_x_waves", 8):
+        got = engine.spectra(iq, 1024, k_avg=k_avg, f64=True, rows_f32=rows_f32)
+    with engine.option("f64_x_waves", 1):
+        one = engine.spectra(iq, 1024, k_avg=k_avg, f64=True, rows_f32=rows_f32)
+    assert engine.get_option("f64_x_waves") == 0
+    assert np.array_equal(got, one)
+    ref = oracle.batch_spectra_u8(iq, 1024, K=k_avg, nthreads=8)
+    assert rel_err(got, ref, EPS_STRICT).max() <= (2.0 ** -24 * 1.001 if rows_f32 else STRICT_F64)
+
+
+def test_x1024_eight_wavefront_db_and_payload_rows(engine, oracle):
+    from rtlws import synth
+    iq = synth.tone_noise_iq(3000, 1024, seed=41)
+    ref = oracle.batch_spectra_u8(iq, 1024, nthreads=8)
+    with engine.option("f64_x_waves", 8):
+        db = engine.spectra(iq, 1024, f64=True, output="mean_db")
+        pay = engine.spectra(iq, 1024, f64=True, output="payload_u8", gain_db=15)
+    ok = ref > 1e-9 * ref.max(axis=1, keepdims=True)
+    assert np.abs(db - 10 * np.log10(ref))[ok].max() <= 1e-9
+    assert np.array_equal(pay, np.stack([oracle.spectrum_payload(r, 1, 15) for r in ref]))

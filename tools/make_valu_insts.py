@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def pmc(workload):
     """the newest committed counter file of the workload (the kernel a line is priced with)"""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (tag, workload))
         if os.path.exists(f):
             return json.load(open(f))["counters"]

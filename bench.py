@@ -896,6 +896,33 @@ def plumbing_main(args):
     return 0 if world == args.gpus else 3
 
 
+def cpus_of_cpulist(text):
+    """"0-3,8,10-11" -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.replace(" ", "").split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_rank_to_its_gpu(rtlws, device, describe=None):
+    """Restrict this process to the CPUs of `device`'s NUMA node that its mask already allows; returns what was
+    learnt and done ({"numa_node", "bus_id", "cpus_pinned"}).  Nothing known, or nothing of the node inside the
+    mask: the process keeps its mask (cpus_pinned 0)."""
+    t = (describe or rtlws.topo_describe)(device)
+    info = {"numa_node": -1, "bus_id": "", "cpus_pinned": 0}
+    if t is None:
+        return info
+    info["numa_node"], info["bus_id"] = int(t.numa_node), t.bus_id.decode()
+    want = set(cpus_of_cpulist(t.cpulist.decode())) & os.sched_getaffinity(0)
+    if want:
+        os.sched_setaffinity(0, want)
+        info["cpus_pinned"] = len(want)
+    return info
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
@@ -944,6 +971,11 @@ def main(argv=None):
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # One process per GPU: under N > 1 each rank keeps to the CPUs of its own GPU's NUMA node (include/rtlws_topo.h),
+    # so that on a two-socket node no rank's launches, events and barriers cross the sockets.  A one-GPU job keeps
+    # its whole mask: its cpu_baseline leg is meant to see the job's cores.
+    rank_topology = pin_rank_to_its_gpu(rtlws, local_rank) if world > 1 else None
+
     eng = rtlws.Engine(local_rank)
     ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
            "rank": rank, "device": device,
@@ -990,6 +1022,8 @@ def main(argv=None):
                     "max_rel_err_floor1e-5": x["parity"].get("max_rel_err_floor1e-5"),
                     "algorithmic_bytes_per_spectrum": 6144}
 
+    if rank == 0 and rank_topology is not None:
+        result.setdefault("per_rank", {})["rank0_topology"] = rank_topology
     rc = 0
     if rank == 0 and rehearsal():
         result["rehearsal"] = ("RTLWS_BENCH_REHEARSAL=1: %d ranks share %d device(s) over gloo -- the N-rank code path, "

@@ -241,3 +241,28 @@ def test_parity_block_single_frame_db_rows_are_bounded_within_50_db(oracle):
     # f64 rows are bounded on every bin
     out = bench.parity_block(np, oracle, wl, iq, 10 * np.log10(ref), 4, f64=True)
     assert out["max_abs_db_err"] < 1e-12
+
+
+def test_rank_pinning_helper(built):
+    """bench.py under N > 1: every rank keeps to its own GPU's NUMA node (include/rtlws_topo.h); here with a faked
+    description, in a child process so that this one keeps its mask."""
+    import subprocess
+    code = """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import bench, rtlws
+assert bench.cpus_of_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and bench.cpus_of_cpulist("") == []
+allowed = sorted(os.sched_getaffinity(0))
+keep = allowed[:max(1, len(allowed) // 2)]
+class T: numa_node = 1; bus_id = b"0000:15:00.0"; cpulist = (",".join(map(str, keep)) + ",4000").encode()
+info = bench.pin_rank_to_its_gpu(rtlws, 1, describe=lambda d: T)
+assert info == {"numa_node": 1, "bus_id": "0000:15:00.0", "cpus_pinned": len(keep)}, info
+assert sorted(os.sched_getaffinity(0)) == keep
+class Far: numa_node = 0; bus_id = b"x"; cpulist = b"4001-4005"
+assert bench.pin_rank_to_its_gpu(rtlws, 0, describe=lambda d: Far)["cpus_pinned"] == 0
+assert sorted(os.sched_getaffinity(0)) == keep
+assert bench.pin_rank_to_its_gpu(rtlws, 0, describe=lambda d: None) == {"numa_node": -1, "bus_id": "", "cpus_pinned": 0}
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "rtl-ws_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

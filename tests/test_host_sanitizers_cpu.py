@@ -44,7 +44,7 @@ def test_threaded_host_layer_under_thread_sanitizer(tmp_path, zero_copy_out):
 def test_threaded_host_layer_under_address_and_ub_sanitizers(tmp_path):
     r = _build_and_run(tmp_path, "address,undefined",
                        {"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1",
-                        "RTLWS_CBB_ALL_FRAMES": "2"})          # the Welch mode of cbb_gpu.c on this pass
+                        "RTLWS_CBB_ALL_FRAMES": "2", "FAKE_HIP_DEVICES": "8"})   # the Welch mode of cbb_gpu.c, eight fake devices
     text = r.stdout + r.stderr
     assert not re.search(r"AddressSanitizer|LeakSanitizer|runtime error", text), text[-6000:]
     assert r.returncode == 0 and "host_stress: 0 failure(s)" in r.stdout, text[-3000:]

@@ -85,7 +85,8 @@ int rtlws_engine_device(const rtlws_engine* e);
  *   "f64_x1024"         [RTLWS_F64_X1024]         0: rectangular 1024-point cmplx_u8 frames stay on the
  *                                                 two-transposition f64 kernel
  *   "f64_x_waves"       [RTLWS_F64_X_WAVES]       wavefronts per workgroup of the one-transposition f64 kernel:
- *                                                 0 by batch size (8 from 32 rows per CU on), 1, 8
+ *                                                 0 by batch size (8 from 32 rows per CU on), 1, 8; 12 = the
+ *                                                 three-per-SIMD measurement form (K = 1 power sums; slower)
  *   "cic_direct"        [RTLWS_CIC_DIRECT]        1: per-lane loads for every CIC factor but 8
  *   "cic_round"         [RTLWS_CIC_ROUND]         1 | 2 | 4: LDS staging depth of the generic factors
  *   "split"             [RTLWS_SPLIT]             Q = 1 .. 8 (default 1): rtlws_spectra_batch / _f64 cut a batch's

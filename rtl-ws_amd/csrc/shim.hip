@@ -511,7 +511,7 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
-    else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
+    else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8 || value == 12) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
     else if (k == "split") {
@@ -991,7 +991,7 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
             // wavefronts take the workgroup's rows one at a time (spectrum_f64_1024x.hip, WAVES)
             int waves = e->opt.f64_x_waves;
             if (waves == 0) waves = (pp.ngroups >= 32L * e->cu_count) ? 8 : 1;
-            if (waves == 8) blocks = e->cu_count;
+            if (waves >= 8) blocks = e->cu_count;
             return rtlws::launch_spectra_f64_1024x(pp, (int)blocks, waves, s);
         }
         switch (d->n_fft) {

@@ -75,9 +75,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     constexpr int N = 1024;
     static_assert(!(ROWF32 && OUT == OUT_PAYLOAD), "payload rows are bytes in either form");
     static_assert(WAVES == 1 || WAVES % 4 == 0, "whole wavefronts per SIMD");
+    static_assert(WAVES != 12 || (KONE && OUT == OUT_SUM), "the three-per-SIMD form exists for the measured case only");
     extern __shared__ __attribute__((aligned(16))) double2 lds_all[];
-    double2* const ldsd = lds_all + (WAVES == 1 ? 0 : (threadIdx.x >> 6) * (17 * 64));     // this wavefront's own slice
-    unsigned* const row_counter = reinterpret_cast<unsigned*>(lds_all + WAVES * 17 * 64);    // (WAVES > 1)
+    // WAVES = 12 (three wavefronts per SIMD; a measurement): <= 168 VGPRs and 160 KiB / 12 of LDS per
+    // wavefront -- the inner twiddles live in LDS ([slot][lane], 16 KiB, shared by the twelve) instead of 64 VGPRs,
+    // and the transposition goes through a 9 KiB slice in two 8-byte halves (re, then im; rows of 16 padded to 18
+    // doubles: 16-byte aligned ds_read_b128, conflict-free either way)
+    constexpr bool W12 = (WAVES == 12);
+    constexpr int SLICE_F2 = W12 ? (64 * 18) / 2 : 17 * 64;           // double2 elements per wavefront
+    double2* const twb_lds = lds_all;                                  // (W12) [16][64]
+    double2* const ldsd = lds_all + (W12 ? 1024 : 0) + (WAVES == 1 ? 0 : (threadIdx.x >> 6) * SLICE_F2);   // this wavefront's own slice
+    unsigned* const row_counter = reinterpret_cast<unsigned*>(lds_all + (W12 ? 1024 : 0) + WAVES * SLICE_F2);    // (WAVES > 1)
 
     const int t = threadIdx.x & 63;
     const int K = KONE ? 1 : p.k_avg;
@@ -86,6 +94,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     long g = (long)blockIdx.x + (WAVES == 1 ? 0L : (long)(threadIdx.x >> 6) * gridDim.x);
     if constexpr (WAVES > 1) {
         if (threadIdx.x == 0) *row_counter = WAVES;
+        if constexpr (WAVES == 12) {
+            for (int e = threadIdx.x; e < 1024; e += 64 * WAVES) twb_lds[(e & 15) * 64 + (e >> 4)] = p.twxb[e];   // [lane][slot] -> [slot][lane]
+        }
         __syncthreads();                                        // the only barrier of the kernel
     }
     // the row after `cur`: WAVES = 1 strides, WAVES > 1 takes the workgroup's next undone row (lane 0's LDS
@@ -119,15 +130,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     if (g < ngroups) load_raw(g * K);
 
     // lane constants, resident for the life of the (persistent) workgroup
-    f2 twA[8], twB[16];
+    f2 twA[8], twB[W12 ? 1 : 16];
 #pragma unroll
     for (int m = 0; m < 8; ++m) twA[m] = p.twxa[(t >> 4) * 8 + m];
+    if constexpr (!W12) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) twB[s] = p.twxb[t * 16 + s];
+        for (int s = 0; s < 16; ++s) twB[s] = p.twxb[t * 16 + s];
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(twA[m].x), "v"(twA[m].y));      // retired before the loop
+    if constexpr (!W12) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) asm volatile("" ::"v"(twB[s].x), "v"(twB[s].y));
+        for (int s = 0; s < 16; ++s) asm volatile("" ::"v"(twB[s].x), "v"(twB[s].y));
+    }
 
     const int wp = t >> 4, wc = t & 15;         // writer side of the transposition: lane (p, c)
 
@@ -191,8 +206,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 #endif
             // inner twiddles W_256^(c q) x the lane constant W_1024^(p c) x 1/128
 #ifndef RTLWS_F64_ABL_NOTWB
+            if constexpr (W12) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twB[s]);
+                for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twb_lds[s * 64 + t]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twB[s]);
+            }
 #else
 #pragma unroll
             for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(v[s].x), "+v"(v[s].y));
@@ -205,6 +225,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             // RTLWS_X_LDS_ORDER 0: wavefront-scope fences (the compiler may spread the writes over pass A's
             // tail and start pass B under the reads); 2: workgroup-scope fences, i.e. what __syncthreads() is
             // around its s_barrier -- writes retired (lgkmcnt(0)) before the reads are issued
+            if constexpr (W12) {
+                double* const half = reinterpret_cast<double*>(ldsd);       // 64 rows of 18 doubles
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) half[18 * (4 * rev16(s) + wp) + wc] = part ? v[s].y : v[s].x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        const double2 two = *reinterpret_cast<const double2*>(half + 18 * t + c);
+                        if (part) { v[c].y = two.x; v[c + 1].y = two.y; }
+                        else { v[c].x = two.x; v[c + 1].x = two.y; }
+                    }
+                }
+            } else {
 #if RTLWS_X_LDS_ORDER == 2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
@@ -222,6 +261,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 #endif
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = ldsd[17 * t + c];
+            }
 #endif
 
             // ---- pass B: radix-16 over c; slot s holds q' = rev16(s): bin k = 64 q' + t
@@ -305,7 +345,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 }
 
 // LDS: one 16 x 17 x 64-byte transposition slice per wavefront (+ the row counter)
-constexpr size_t x_lds_bytes(int waves) { return (size_t)waves * 16 * 17 * 64 + (waves > 1 ? 16 : 0); }
+constexpr size_t x_lds_bytes(int waves)
+{
+    return waves == 12 ? (size_t)16384 + (size_t)waves * 64 * 18 * 8 + 16       // inner twiddles + twelve 9 KiB slices
+                       : (size_t)waves * 16 * 17 * 64 + (waves > 1 ? 16 : 0);
+}
 
 template <int OUT, bool ROWF32, int WAVES>
 static hipError_t launch_x_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
@@ -347,9 +391,32 @@ static hipError_t launch_x_w(const SpectraParamsF64& p, int blocks, hipStream_t 
 }
 
 // waves = 1: `blocks` one-wavefront workgroups; waves = 8: `blocks` workgroups of eight wavefronts (one per CU)
+// (waves = 12: three wavefronts per SIMD, K = 1 power sums only -- the measurement of DESIGN.md 6.3; anything else
+// falls back to eight)
+static hipError_t launch_x_12(const SpectraParamsF64& p, int blocks, hipStream_t st)
+{
+    constexpr size_t lds_bytes = x_lds_bytes(12);
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, true, 12>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, false, 12>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    if (blocks <= 0) return hipSuccess;
+    if (p.rows_f32) hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, true, true, 12>), dim3(blocks), dim3(768), lds_bytes, st, p);
+    else hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, true, false, 12>), dim3(blocks), dim3(768), lds_bytes, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_spectra_f64_1024x(const SpectraParamsF64& p, int blocks, int waves, hipStream_t st)
 {
-    return waves == 8 ? launch_x_w<8>(p, blocks, st) : launch_x_w<1>(p, blocks, st);
+    if (waves == 12 && p.k_avg == 1 && p.out_mode == OUT_SUM) return launch_x_12(p, blocks, st);
+    return waves >= 8 ? launch_x_w<8>(p, blocks, st) : launch_x_w<1>(p, blocks, st);
 }
 
 }  // namespace rtlws

@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "rtlws_internal.h"
 #include "fft_regs_f64.h"
 
@@ -356,17 +358,17 @@ static hipError_t launch_x_k(const SpectraParamsF64& p, int blocks, hipStream_t 
 {
     constexpr size_t lds_bytes = x_lds_bytes(WAVES);
     if constexpr (lds_bytes > 65536) {      // once per instantiation and device
-        static bool done[64];
+        static std::atomic<bool> done[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!done[dev]) {
+        if (!done[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT, true, ROWF32, WAVES>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e == hipSuccess && OUT == OUT_SUM)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, false, ROWF32, WAVES>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
-            done[dev] = true;
+            done[dev].store(true, std::memory_order_release);
         }
     }
     if (blocks <= 0) return hipSuccess;      // rtlws_engine_prepare_f64: the attribute only, nothing enqueued
@@ -396,16 +398,16 @@ static hipError_t launch_x_w(const SpectraParamsF64& p, int blocks, hipStream_t 
 static hipError_t launch_x_12(const SpectraParamsF64& p, int blocks, hipStream_t st)
 {
     constexpr size_t lds_bytes = x_lds_bytes(12);
-    static bool done[64];
+    static std::atomic<bool> done[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!done[dev]) {
+    if (!done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, true, 12>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, false, 12>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        done[dev] = true;
+        done[dev].store(true, std::memory_order_release);
     }
     if (blocks <= 0) return hipSuccess;
     if (p.rows_f32) hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, true, true, 12>), dim3(blocks), dim3(768), lds_bytes, st, p);

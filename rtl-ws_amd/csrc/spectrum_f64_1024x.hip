@@ -163,6 +163,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             // no: it reaches exactly X[0] (a constant sequence has a single non-zero bin), which is
             // never output (src/spectrum.c:31); it is kept, as in the other kernels.
             unsigned y[16];                     // y[4 b + pp]
+#ifdef RTLWS_F64_ABL_NOPASS0      // (energy-attribution build: no integer radix-4)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = raw[r];
+#else
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 pk_i16 x[4];
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                 y[4 * b + 2] = __builtin_bit_cast(unsigned, (pk_i16)(s0 - s2));
                 y[4 * b + 3] = __builtin_bit_cast(unsigned, (pk_i16)(s1 - rot));
             }
+#endif
             {
                 long nf = frame + 1;
                 if (kf + 1 == K) nf = g_next * K;
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 
             // ---- cross-row 4 x 4 transpose (lane row <-> p): afterwards lane (row p, column c)
             // holds y_p[c + 16 (4 b + g)] in y[4 b + g]
+#ifndef RTLWS_F64_ABL_NOSWAP      // (energy-attribution build: no cross-row transpose)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 swap_rows16(y[4 * b + 0], y[4 * b + 1]);
@@ -196,10 +202,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                 swap_rows32(y[4 * b + 0], y[4 * b + 2]);
                 swap_rows32(y[4 * b + 1], y[4 * b + 3]);
             }
+#endif
             f2 v[16];
+#ifdef RTLWS_F64_ABL_NOCVT        // (energy-attribution build: the sample bits pasted into doubles near 1, no conversion)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = mk(__hiloint2double(0x3ff00000, (int)y[r]), __hiloint2double(0x3ff80000, (int)y[r]));
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 v[r] = mk((double)(short)(y[r] & 0xffffu), (double)((int)y[r] >> 16));
+#endif
 
             // ---- pass A: radix-16 over r with the geometric pre-twiddle (W_64^p)^r absorbed;
             // slot s holds index q = rev16(s)
@@ -278,7 +291,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                     acc[u] = KONE ? pw : acc[u] + pw;
                     wdc = KONE ? pw : fma((double)(K - kf), pw, wdc);
                 } else if constexpr (KONE) {
+#ifdef RTLWS_F64_ABL_NOPOW       // (energy-attribution build: no |X|^2)
+                    acc[u] = v[u].x;
+                    asm volatile("" ::"v"(v[u].y));
+#else
                     acc[u] = fma(v[u].y, v[u].y, v[u].x * v[u].x);
+#endif
                 } else {
                     acc[u] = fma(v[u].y, v[u].y, fma(v[u].x, v[u].x, acc[u]));
                 }

@@ -1,6 +1,10 @@
 #!/bin/bash
 # free re-spellings of spectrum_f64_1024x under the energy accumulator (mJ per launch, 15 000 launches, alternating):
-# the sixteen 256-byte pieces of a row stored in address order; pass B as multiply-then-butterfly
+# the sixteen 256-byte pieces of a row stored in address order; pass B as multiply-then-butterfly.  Builds:
+#   make -C rtl-ws_amd xvariant NAME=xe_fft16plain EXTRA=-DRTLWS_FFT16_FMA=0
+#   xe_ascst: the store loop of the kernel's epilogue run over uu = 0 .. 15 with u = rev16(uu ^ 8) (piece uu is held in
+#   slot rev16(uu ^ 8): rev16 is an involution) -- a six-line #ifdef that was removed again after this measurement
+#   (no difference: hipcc orders the stores by when their values are ready; profiles/r05_energy_variants_not_adopted.txt)
 OUT=gpurun_out/r05_energy_variants.txt; : > $OUT
 V=$PWD/rtl-ws_amd/lib/variants
 for rep in 1 2 3; do

@@ -31,7 +31,7 @@ cores -- one thread, the job's CPU quota and the whole affinity mask; `value` is
 the fastest of them, `cores` the thread count that produced it -- on a bounded
 sample of the same workload; `extra_workloads` carries the same measurement (fewer
 steps) for BASELINE.json configs[2] and configs[3], the reference's own CIC factor,
-and the f32 fast mode.
+the f32 fast mode, and configs[1] again with the engine option "split" = 2 (--split).
 """
 import argparse
 import json
@@ -96,11 +96,10 @@ FAST_MODE = "batched_1024pt_64k_frames"          # the same frames in f32 arithm
 # then configs[1] in f32 (fast mode) and with f64 rows, and configs[3] in the reference's arithmetic
 EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", FAST_MODE, "batched_1024pt_64k_frames_f64",
                    "cic8_2048pt_f64")
-# (workload, Q) pairs measured again with the engine option "split" on the default line: none -- the option is
-# slower than one launch (0.41 against 0.45, profiles/r05_split_option_and_large_launches.txt) and, with one more
-# HIP stream in the process than hardware queues, pathologically so (14 ms per batch); `--split Q` measures it
-# on request
-EXTRA_SPLIT = ()
+# ... and these again with the engine option "split" (rows as Q concurrent launches joined back into the stream;
+# wall-clock fractions: per-dispatch averages overlap).  Slower than one launch (0.42 against 0.46, 0.54 against 0.65:
+# profiles/r05_split_priority_queues.txt) -- on the line so that the cost is visible, as VERDICT r4 asked
+EXTRA_SPLIT = ((HEADLINE, 2), (FAST_MODE, 2))
 # ... and these carry their own cpu_baseline (the BASELINE.json configurations other than the headline)
 EXTRA_CPU_BASELINE = {"hann_4096pt_k8_db": 0.2, "cic8_2048pt": 0.2}      # name -> budget_scale
 EXTRA_STEPS = 200

@@ -94,13 +94,14 @@ int rtlws_engine_device(const rtlws_engine* e);
  *       caller's stream, the others on Q - 1 engine-owned queues forked from it and joined back into it
  *       by events, so the caller still orders against its own stream only; rows bit-identical to one
  *       launch; batches of fewer than 16 rows per CU and range are not cut.  The queues and events are
- *       created when the option is set (never on a launch path: a cut batch is capturable).  MEASURED
- *       (one MI355X, 65 536 x 1024-point frames, profiles/r05_split.txt): Q = 2 is SLOWER than one launch
- *       -- 0.41 against 0.45 of the HBM roofline in f64 arithmetic, 0.53 against 0.64 in f32: the fork and
- *       the join are cross-queue dependencies that cost more per batch than the overlapped fill and drain
- *       phases win -- and with more HIP streams in the process than hardware queues (4 by default; five at
- *       Q = 3 under bench.py) a batch takes 14 ms.  The overlap pays only for INDEPENDENT batches on
- *       independent queues (rtlws_multi.h, shards per device); the option stays for callers who can
+ *       created when the option is set (never on a launch path: a cut batch is capturable), the queues at
+ *       the highest stream priority: priority classes have hardware queues of their own, and a side queue
+ *       that shared a hardware queue with the stream it forks from took 14 ms per batch.  MEASURED (one
+ *       MI355X, 65 536 x 1024-point frames, profiles/r05_split_priority_queues.txt): SLOWER than one launch
+ *       -- Q = 2: 0.42 against 0.46 of the HBM roofline in f64 arithmetic, 0.54 against 0.65 in f32; Q = 3, 4:
+ *       0.27-0.39 / 0.32: the fork and the join are cross-queue dependencies that cost more per batch than the
+ *       overlapped fill and drain phases win.  The overlap pays only for INDEPENDENT batches on independent
+ *       queues (rtlws_multi.h, shards per device: f32 0.66 -> 0.71); the option stays for callers who can
  *       measure their own case.  With Q > 1 an engine's launches must come from one thread at a time.
  * set: 0, -1 for an unknown name, -3 if the queues of "split" cannot be created.  get: the value ("cu_count" is
  * readable too), -2 if unknown.  An option must not be changed while another thread launches on the same engine

@@ -375,9 +375,16 @@ int split_prepare(rtlws_engine* e, int q)
     if (q > kMaxSplit) q = kMaxSplit;
     HIP_TRY(hipSetDevice(e->device), -3);
     if (q > 1 && !e->split_fork) HIP_TRY(hipEventCreateWithFlags(&e->split_fork, hipEventDisableTiming), -3);
+    // The side queues are created at the HIGHEST stream priority: HIP multiplexes the streams of one priority
+    // over a few hardware queues (4 by default), and a side queue that shares a hardware queue with the stream it
+    // waits for (or that waits for it) stalls for milliseconds (profiles/r05_split_option_and_large_launches.txt:
+    // 14 ms per batch with five normal-priority streams in the process); priority classes have hardware queues
+    // of their own.
+    int prio_low = 0, prio_high = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;
     while (e->split_ready < q - 1) {
         const int i = e->split_ready;
-        HIP_TRY(hipStreamCreateWithFlags(&e->split_q[i], hipStreamNonBlocking), -3);
+        HIP_TRY(hipStreamCreateWithPriority(&e->split_q[i], hipStreamNonBlocking, prio_high), -3);
         HIP_TRY(hipEventCreateWithFlags(&e->split_join[i], hipEventDisableTiming), -3);
         e->split_ready = i + 1;
     }

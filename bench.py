@@ -30,8 +30,10 @@ using the ALGORITHMIC bytes (2*N*R in + 4*N/K out per frame, SURVEY.md §8d);
 cores -- one thread, the job's CPU quota and the whole affinity mask; `value` is
 the fastest of them, `cores` the thread count that produced it -- on a bounded
 sample of the same workload; `extra_workloads` carries the same measurement (fewer
-steps) for BASELINE.json configs[2] and configs[3], the reference's own CIC factor,
-the f32 fast mode, and configs[1] again with the engine option "split" = 2 (--split).
+steps) for BASELINE.json configs[2] and configs[3] -- each in f32 AND in the reference's
+arithmetic, each with its own cpu_baseline -- the reference's own CIC factor and the f32
+fast mode of configs[1]; `roofline.box` characterises the chip itself (a fixed v_fma_f64
+stream at the power cap: the clock and the watts the governor gives it).
 """
 import argparse
 import json
@@ -94,14 +96,13 @@ HEADLINE = "batched_1024pt_64k_frames_f64c_f32o"
 FAST_MODE = "batched_1024pt_64k_frames"          # the same frames in f32 arithmetic: narrower than the reference
 # configs[2], configs[3] and the reference's own decimation factor ride along on the default line,
 # then configs[1] in f32 (fast mode) and with f64 rows, and configs[3] in the reference's arithmetic
-EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "cic8_2048pt", "cic12_2048pt", FAST_MODE, "batched_1024pt_64k_frames_f64",
-                   "cic8_2048pt_f64")
-# ... and these again with the engine option "split" (rows as Q concurrent launches joined back into the stream;
-# wall-clock fractions: per-dispatch averages overlap).  Slower than one launch (0.42 against 0.46, 0.54 against 0.65:
-# profiles/r05_split_priority_queues.txt) -- on the line so that the cost is visible, as VERDICT r4 asked
-EXTRA_SPLIT = ((HEADLINE, 2), (FAST_MODE, 2))
-# ... and these carry their own cpu_baseline (the BASELINE.json configurations other than the headline)
-EXTRA_CPU_BASELINE = {"hann_4096pt_k8_db": 0.2, "cic8_2048pt": 0.2}      # name -> budget_scale
+EXTRA_WORKLOADS = ("hann_4096pt_k8_db", "hann_4096pt_k8_db_f64c_f32o", "cic8_2048pt", "cic8_2048pt_f64", "cic12_2048pt",
+                   FAST_MODE, "batched_1024pt_64k_frames_f64")
+# ... and these carry their own cpu_baseline (the BASELINE.json configurations other than the headline, in f32 and
+# in the reference's arithmetic: the CPU path -- the f64 oracle -- is the same for both, so it is timed once per
+# configuration and the block shared)
+EXTRA_CPU_BASELINE = {"hann_4096pt_k8_db": 0.2, "hann_4096pt_k8_db_f64c_f32o": 0.2,
+                      "cic8_2048pt": 0.2, "cic8_2048pt_f64": 0.2}      # name -> budget_scale
 EXTRA_STEPS = 200
 
 
@@ -352,32 +353,21 @@ def gather_ranks(torch, dist, value, device=None):
     return [float(x[0]) for x in out]
 
 
-def energy_counter(device_index=0):
-    """Joules of the package energy accumulator (rocm_smi rsmi_dev_energy_count_get), or None."""
-    global _SMI
-    import ctypes as C
+def energy_counter_for(rtlws, device_index):
+    """The package energy accumulator of HIP device `device_index`, found by its PCI bus id (rocm_smi numbers
+    every physical GPU and ignores HIP_VISIBLE_DEVICES: a HIP ordinal is not an rsmi index), or None -- the energy
+    leg is then dropped, never read off another GPU.  rtl-ws_amd/rtlws/energy.py."""
     try:
-        if _SMI is None:
-            _SMI = C.CDLL("librocm_smi64.so")
-            if _SMI.rsmi_init(C.c_uint64(0)) != 0:
-                _SMI = False
-        if not _SMI:
-            return None
-        cnt, res, ts = C.c_uint64(0), C.c_float(0), C.c_uint64(0)
-        if _SMI.rsmi_dev_energy_count_get(C.c_uint32(device_index), C.byref(cnt), C.byref(res), C.byref(ts)) != 0:
-            return None
-        return cnt.value * res.value * 1e-6
-    except OSError:
-        _SMI = False
+        from rtlws import energy
+        return energy.for_hip_device(rtlws, device_index)
+    except Exception:
         return None
 
 
-_SMI = None
 ENERGY_LAUNCHES = 600          # launches of the energy leg (after the timed region, untimed)
 
 
-def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0,
-                 split=1):
+def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0):
     """Allocate `sets` rotating buffer sets, run max(warmup, SETTLE_LAUNCHES)
     untimed launches, time exactly `steps` launches between barrier +
     synchronise on both sides (wall clock -> value) and between HIP events on
@@ -420,10 +410,6 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     torch.cuda.synchronize()
     L = rtlws.hip_lib()
     launch = eng.spectra_batch_f64 if f64 else eng.spectra_batch
-    # engine option "split": the batch's rows as `split` concurrent launches on engine-owned queues, joined
-    # back into this stream (include/rtlws_hip.h); 1 = one launch, the rocprof-checkable figure
-    split_before = eng.get_option("split")
-    eng.set_option("split", split)
 
     def step(i):
         s = i % sets
@@ -491,25 +477,31 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     # energy leg (one-GPU jobs; after the clock has stopped): the package energy accumulator around
     # ENERGY_LAUNCHES more launches of the same step -- joules per launch and the power they ran at
     energy = None
-    if world == 1 and ctx.get("energy", True):
-        j0 = energy_counter(getattr(device, "index", 0) or 0)
+    ec = ctx.get("energy_counter") if (world == 1 and ctx.get("energy", True)) else None
+    if ec is not None:
+        j0 = ec.joules()
         if j0 is not None:
             tq0 = time.perf_counter()
             for i in range(ENERGY_LAUNCHES):
                 step(i)
             torch.cuda.synchronize()
             tq1 = time.perf_counter()
-            j1 = energy_counter(getattr(device, "index", 0) or 0)
+            j1 = ec.joules()
             if j1 is not None and j1 > j0:
                 energy = {"mj_per_launch": 1e3 * (j1 - j0) / ENERGY_LAUNCHES, "watts": (j1 - j0) / (tq1 - tq0),
-                          "launches": ENERGY_LAUNCHES,
-                          "source": "rocm_smi rsmi_dev_energy_count_get around %d further launches after the timed "
-                                    "region (package energy accumulator; not part of `value`)" % ENERGY_LAUNCHES}
-    eng.set_option("split", split_before)
+                          "launches": ENERGY_LAUNCHES, "bus_id": ec.bus_id, "rsmi_index": ec.index,
+                          "source": "rocm_smi rsmi_dev_energy_count_get of the GPU at this bus id around %d further "
+                                    "launches after the timed region (package energy accumulator; not part of "
+                                    "`value`)" % ENERGY_LAUNCHES}
     rdev = ctx.get("reduce_device", device)
     elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], rdev)
     per_rank_own = gather_ranks(torch, dist, 1e3 * own_elapsed / steps, rdev)
     per_rank_ev = gather_ranks(torch, dist, ev_ms / steps, rdev)
+    # ... and WHERE each rank ran: device, PCI bus id, NUMA node, CPUs it pinned itself to (include/rtlws_topo.h),
+    # with its own clock and times -- the first real N-GPU record proves its placement by itself
+    ranks = gather_objects(dist, placement_record(rank, ctx.get("local_rank", 0), ctx.get("rank_topology"),
+                                                  sclk_ghz=sclk_ghz, ms_per_step_own=1e3 * own_elapsed / steps,
+                                                  event_ms_per_step=ev_ms / steps)) if world > 1 else None
     ev_ms = ev_ms_max
 
     result = None
@@ -551,16 +543,14 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                        "k_avg": k_avg, "window": window, "output": output, "cic_r": cic_r,
                        "input": "cmplx_u8 %s, device-resident, %d rotating sets"
                                 % ("uniform random bytes" if ctx.get("input") == "uniform" else "tone(0.6)+noise(0.05)", sets),
-                       "sharding": "independent frames per GPU, no collective", "split": split},
+                       "sharding": "independent frames per GPU, no collective"},
             # frac      : algorithmic bytes / average launch duration between HIP events recorded on the
             #             launch stream around the timed launches (the kernel's own time)
             # frac_wall : the same bytes / ms_per_step, the host wall clock `value` is computed from
             #             (barrier + synchronise on both sides; includes the sync and launch overheads)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "frac_clock": "hip_events_on_launch_stream" if split == 1 else
-                                       "hip_events_on_launch_stream around batches of %d concurrent launches: the batch's "
-                                       "duration, not one kernel's (per-dispatch averages overlap)" % split,
+                         "frac_clock": "hip_events_on_launch_stream",
                          "achieved_wall": achieved_wall, "frac_wall": achieved_wall / HBM_PEAK_GBS,
                          "frac_wall_clock": "host_perf_counter_ms_per_step",
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -580,7 +570,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                 result["roofline"].update(vf)
         if world > 1:
             # every rank's own figures, so a scaling loss is visible in this one line
-            result["per_rank"] = {"ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
+            result["per_rank"] = {"ranks": ranks,
+                                  "ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
                                                       "all": per_rank_own},
                                   "event_ms_per_step": {"min": min(per_rank_ev), "max": max(per_rank_ev),
                                                         "all": per_rank_ev},
@@ -599,7 +590,15 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             result["parity"]["failed"] = bad
 
         if cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_block(np, po, wl, ins[0], frames, cpu_budget_scale)
+            # the CPU path is the f64 oracle whatever the GPU rows are: one timing per configuration and run
+            key = (n_fft, k_avg, window, output, cic_r, frames)
+            cache = ctx.setdefault("cpu_baseline_cache", {})
+            if key not in cache:
+                cache[key] = (name, cpu_baseline_block(np, po, wl, ins[0], frames, cpu_budget_scale))
+            first, block = cache[key]
+            result["cpu_baseline"] = block if first == name else dict(
+                block, shared_with=first, sample=block["sample"] + " [timed once in this run, beside %s: the same "
+                "frames through the same f64 CPU path]" % first)
     del ins, outs
     torch.cuda.empty_cache()
     return result
@@ -883,16 +882,25 @@ def plumbing_main(args):
         dist.barrier()
     elapsed, slowest = max_over_ranks(torch, dist, [time.perf_counter() - t0, float(rank)])
     per_rank_own = gather_ranks(torch, dist, 1e3 * own / args.steps)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    topo = None
+    if world > 1:
+        import rtlws
+        topo = pin_rank_to_its_gpu(rtlws, local_rank, planned_topology(rtlws, local_rank) or (lambda _d: None))
+    ranks = gather_objects(dist, placement_record(rank, local_rank, topo, sclk_ghz=None,
+                                                  ms_per_step_own=1e3 * own / args.steps, event_ms_per_step=None))
+    clashes = check_distinct_devices(ranks) if rank == 0 else []
     if rank == 0:
         print(json.dumps({"metric": "plumbing only (no GPU step)", "value": whole_job_rate(world, args.steps, frames, elapsed),
                           "n_gpus": world, "steps": args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
                           "slowest_rank": slowest, "asked_gpus": args.gpus, "data": "none",
-                          "per_rank": {"ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
+                          "per_rank": {"ranks": ranks, "device_clashes": clashes,
+                                       "ms_per_step_own": {"min": min(per_rank_own), "max": max(per_rank_own),
                                                            "all": per_rank_own}}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return 0 if world == args.gpus else 3
+    return 3 if world != args.gpus else 6 if clashes else 0
 
 
 def cpus_of_cpulist(text):
@@ -922,6 +930,84 @@ def pin_rank_to_its_gpu(rtlws, device, describe=None):
     return info
 
 
+def planned_topology(rtlws, local_rank):
+    """--plumbing-cpu and offline planning: RTLWS_BENCH_BUS_IDS (comma list, rank r takes entry r) and
+    RTLWS_BENCH_SYSFS_ROOT describe the rank's device without touching a GPU (include/rtlws_topo.h takes a sysfs
+    root for exactly that); None when they are not set."""
+    ids = [b for b in os.environ.get("RTLWS_BENCH_BUS_IDS", "").split(",") if b]
+    if not ids:
+        return None
+    bus = ids[local_rank % len(ids)]
+    return lambda _device: rtlws.topo_describe(bus_id=bus, sysfs_root=os.environ.get("RTLWS_BENCH_SYSFS_ROOT") or None)
+
+
+def gather_objects(dist, obj):
+    """obj of every rank, in rank order ([obj] when dist is None)."""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def placement_record(rank, local_rank, topo, **figures):
+    """What one rank contributes to per_rank.ranks: where it ran and its own figures."""
+    rec = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(),
+           "device": local_rank if topo is None else topo.get("device", local_rank),
+           "bus_id": (topo or {}).get("bus_id", ""), "numa_node": (topo or {}).get("numa_node", -1),
+           "cpus_pinned": (topo or {}).get("cpus_pinned", 0)}
+    rec.update(figures)
+    return rec
+
+
+def check_distinct_devices(records, allow_shared=False):
+    """One process per GPU: no two ranks of a host on one device (bus id where known, else host + device index).
+    Returns the list of clashes; rank 0 refuses to print an N-GPU line over them unless `allow_shared` (rehearsal)."""
+    seen, clashes = {}, []
+    for r in records:
+        key = (r["host"], r["bus_id"] or "device %d" % r["device"])
+        if key in seen:
+            clashes.append({"ranks": [seen[key], r["rank"]], "host": key[0], "device": key[1]})
+        seen.setdefault(key, r["rank"])
+    return [] if allow_shared else clashes
+
+
+def box_calibration(rtlws, device_index, ec, settle_s=0.15, measure_s=0.25):
+    """roofline.box: what THIS chip gives a fixed, memory-free instruction stream at the package power cap
+    (rtl-ws_amd/bench/box_calib.hip: v_fma_f64 on every SIMD, two wavefronts each) -- the shader clock the governor
+    settles at, the watts (package energy accumulator around the measured launches) and the f64 rate.  The product
+    kernels run at the same cap, and what the cap buys differs from chip to chip (0.443-0.487 of the HBM roofline
+    for the same code): this separates a slow box from a regression.  After the timed region, never in `value`."""
+    import ctypes as C
+
+    class Res(C.Structure):
+        _fields_ = [("sclk_ghz", C.c_double), ("gpu_seconds", C.c_double), ("wall_seconds", C.c_double),
+                    ("wave_instructions", C.c_double), ("launches", C.c_long), ("simds", C.c_int)]
+
+    path = os.path.join(rtlws.LIB_DIR, "librtlws_bench.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.rtlws_box_calib_run.argtypes = [C.c_int, C.c_double, C.POINTER(Res)]
+    r = Res()
+    if lib.rtlws_box_calib_run(device_index, settle_s, C.byref(r)) != 0:       # the governor's transient, unmeasured
+        return None
+    j0 = ec.joules() if ec is not None else None
+    if lib.rtlws_box_calib_run(device_index, measure_s, C.byref(r)) != 0:
+        return None
+    j1 = ec.joules() if ec is not None else None
+    box = {"fma_f64_sclk_ghz_at_cap": r.sclk_ghz,
+           "fma_f64_tflops": 2.0 * 64.0 * r.wave_instructions / r.gpu_seconds / 1e12,
+           "cycles_per_instruction_and_simd": r.sclk_ghz * 1e9 * r.gpu_seconds * r.simds / r.wave_instructions,
+           "seconds": r.gpu_seconds, "launches": int(r.launches),
+           "kernel": "box_calib_kernel: 256 x v_fma_f64 per loop iteration on eight register pairs, 2 wavefronts per "
+                     "SIMD on every CU, no memory traffic (rtl-ws_amd/bench/box_calib.hip); %.2f s settle + this"
+                     % settle_s}
+    if j0 is not None and j1 is not None and j1 > j0:
+        box["watts"] = (j1 - j0) / r.wall_seconds
+    return box
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
@@ -938,9 +1024,7 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, default=0, help="override frames per step (experiments)")
     ap.add_argument("--shards-per-device", type=int, default=1, choices=[1, 2, 3, 4],
                     help="--workload multi_batch: concurrent shards (own queue and host thread) per device")
-    ap.add_argument("--split", type=int, default=1, choices=range(1, 9), metavar="Q",
-                    help="engine option \"split\": every batch's rows as Q concurrent launches on engine-owned queues "
-                         "(wall-clock fraction; 1 = one launch per step, the rocprof-checkable figure)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration (roofline.box)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy leg after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="no probe wavefront beside the timed launches (rocprofv3 --pmc serialises kernels: the "
@@ -973,7 +1057,7 @@ def main(argv=None):
     # One process per GPU: under N > 1 each rank keeps to the CPUs of its own GPU's NUMA node (include/rtlws_topo.h),
     # so that on a two-socket node no rank's launches, events and barriers cross the sockets.  A one-GPU job keeps
     # its whole mask: its cpu_baseline leg is meant to see the job's cores.
-    rank_topology = pin_rank_to_its_gpu(rtlws, local_rank) if world > 1 else None
+    rank_topology = pin_rank_to_its_gpu(rtlws, local_rank, planned_topology(rtlws, local_rank)) if world > 1 else None
 
     eng = rtlws.Engine(local_rank)
     ctx = {"torch": torch, "np": np, "rtlws": rtlws, "eng": eng, "dist": dist, "world": world,
@@ -981,7 +1065,10 @@ def main(argv=None):
            # ONE side stream carries input synthesis and every launch (run_workload, "Stream order")
            "input": args.input, "clock_probe": not args.no_clock_probe, "energy": not args.no_energy,
            "stream": torch.cuda.Stream(device=device),
-           "cu_count": torch.cuda.get_device_properties(device).multi_processor_count}
+           "cu_count": torch.cuda.get_device_properties(device).multi_processor_count,
+           "local_rank": local_rank, "rank_topology": rank_topology,
+           # the package energy accumulator of THIS device, by PCI bus id (one-GPU jobs)
+           "energy_counter": energy_counter_for(rtlws, local_rank) if (world == 1 and not args.no_energy) else None}
 
     # First collective = RCCL's lazy communicator set-up (~16 ms): do it here, not
     # between the warm-up launches and the timed region, where that much idle
@@ -991,17 +1078,28 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     result = run_workload(ctx, args.workload, args.steps, args.warmup, args.sets, args.frames,
-                          cpu_baseline=(world == 1 and not args.no_cpu_baseline), split=args.split)
+                          cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+
+    # what this chip gives a fixed instruction stream at the cap (roofline.box): right behind the headline's energy
+    # leg, the package still at its cap
+    if world == 1 and rank == 0 and not args.no_box and not args.no_energy and ctx["clock_probe"]:
+        try:
+            box = box_calibration(rtlws, local_rank, ctx["energy_counter"])
+        except Exception as ex:            # an auxiliary measurement: the line goes out without it
+            print("bench.py: box calibration failed (%s); continuing without roofline.box" % ex, file=sys.stderr)
+            box = None
+        if box is not None:
+            result["roofline"]["box"] = box
 
     # The default line also carries configs[2], configs[3] and the reference's own CIC
     # factor, measured the same way with fewer steps (rank 0 of a 1-GPU job only).
-    if world == 1 and args.workload == HEADLINE and not args.no_extra and args.frames == 0 and args.split == 1:
+    if world == 1 and args.workload == HEADLINE and not args.no_extra and args.frames == 0:
         extras = []
-        for name, q in [(n, 1) for n in EXTRA_WORKLOADS] + list(EXTRA_SPLIT):
-            with_cpu = q == 1 and name in EXTRA_CPU_BASELINE and not args.no_cpu_baseline
+        for name in EXTRA_WORKLOADS:
+            with_cpu = name in EXTRA_CPU_BASELINE and not args.no_cpu_baseline
             r = run_workload(ctx, name, EXTRA_STEPS, 0, args.sets, cpu_baseline=with_cpu,
-                             cpu_budget_scale=EXTRA_CPU_BASELINE.get(name, 1.0), split=q)
-            x = {"workload": name, "split": q, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                             cpu_budget_scale=EXTRA_CPU_BASELINE.get(name, 1.0))
+            x = {"workload": name, "metric": r["metric"], "value": r["value"], "unit": r["unit"],
                  "dtype": r["dtype"], "steps": r["steps"], "settle_launches": r["settle_launches"],
                  "ms_per_step": r["ms_per_step"], "config": r["config"],
                  "roofline": r["roofline"], "parity": r["parity"]}
@@ -1013,7 +1111,7 @@ def main(argv=None):
         # (src/spectrum.c is double end to end), and <= 1e-4 only under the relaxed floor its parity block
         # names: context beside the headline, not the metric
         for x in extras:
-            if x["workload"] == FAST_MODE and x["split"] == 1:
+            if x["workload"] == FAST_MODE:
                 result["fast_mode_line"] = {
                     "workload": x["workload"], "dtype": x["dtype"], "value": x["value"], "unit": x["unit"],
                     "roofline_frac": x["roofline"]["frac"],
@@ -1021,9 +1119,13 @@ def main(argv=None):
                     "max_rel_err_floor1e-5": x["parity"].get("max_rel_err_floor1e-5"),
                     "algorithmic_bytes_per_spectrum": 6144}
 
-    if rank == 0 and rank_topology is not None:
-        result.setdefault("per_rank", {})["rank0_topology"] = rank_topology
     rc = 0
+    if rank == 0 and world > 1:
+        clashes = check_distinct_devices(result["per_rank"]["ranks"], allow_shared=rehearsal())
+        if clashes:
+            result["per_rank"]["device_clashes"] = clashes
+            print("bench.py: ranks share a device: %s -- not an N-GPU measurement" % json.dumps(clashes), file=sys.stderr)
+            rc = 6
     if rank == 0 and rehearsal():
         result["rehearsal"] = ("RTLWS_BENCH_REHEARSAL=1: %d ranks share %d device(s) over gloo -- the N-rank code path, "
                                "not a measurement" % (world, torch.cuda.device_count()))
@@ -1031,8 +1133,7 @@ def main(argv=None):
         # A parity block that is non-finite or over its bound is a FAILED run: the line is still
         # printed (strict JSON: a non-finite number becomes a string), the exit code says so.
         blocks = [(result["config"]["workload"], result["parity"])]
-        blocks += [(x["workload"] + ("" if x["split"] == 1 else " split %d" % x["split"]), x["parity"])
-                   for x in result.get("extra_workloads", [])]
+        blocks += [(x["workload"], x["parity"]) for x in result.get("extra_workloads", [])]
         failed = {n: b["failed"] for n, b in blocks if b.get("failed")}
         if failed:
             result["parity_failed"] = failed

@@ -32,6 +32,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* librtlws_hip.so is built with -fvisibility=hidden and linked with a version script: these declarations, and
+ * nothing else, are its dynamic symbols (tests/test_abi_cpu.py checks both directions) */
+#pragma GCC visibility push(default)
 
 typedef struct rtlws_engine rtlws_engine;
 
@@ -85,26 +88,16 @@ int rtlws_engine_device(const rtlws_engine* e);
  *   "f64_x1024"         [RTLWS_F64_X1024]         0: rectangular 1024-point cmplx_u8 frames stay on the
  *                                                 two-transposition f64 kernel
  *   "f64_x_waves"       [RTLWS_F64_X_WAVES]       wavefronts per workgroup of the one-transposition f64 kernel:
- *                                                 0 by batch size (8 from 32 rows per CU on), 1, 8; 12 = the
- *                                                 three-per-SIMD measurement form (K = 1 power sums; slower)
+ *                                                 0 by batch size (8 from 32 rows per CU on, where the device's
+ *                                                 LDS limit per workgroup holds their 136 KiB), 1, 8
  *   "cic_direct"        [RTLWS_CIC_DIRECT]        1: per-lane loads for every CIC factor but 8
  *   "cic_round"         [RTLWS_CIC_ROUND]         1 | 2 | 4: LDS staging depth of the generic factors
- *   "split"             [RTLWS_SPLIT]             Q = 1 .. 8 (default 1): rtlws_spectra_batch / _f64 cut a batch's
- *       rows into Q contiguous ranges of whole K-groups and launch them concurrently -- range 0 on the
- *       caller's stream, the others on Q - 1 engine-owned queues forked from it and joined back into it
- *       by events, so the caller still orders against its own stream only; rows bit-identical to one
- *       launch; batches of fewer than 16 rows per CU and range are not cut.  The queues and events are
- *       created when the option is set (never on a launch path: a cut batch is capturable), the queues at
- *       the highest stream priority: priority classes have hardware queues of their own, and a side queue
- *       that shared a hardware queue with the stream it forks from took 14 ms per batch.  MEASURED (one
- *       MI355X, 65 536 x 1024-point frames, profiles/r05_split_priority_queues.txt): SLOWER than one launch
- *       -- Q = 2: 0.42 against 0.46 of the HBM roofline in f64 arithmetic, 0.54 against 0.65 in f32; Q = 3, 4:
- *       0.27-0.39 / 0.32: the fork and the join are cross-queue dependencies that cost more per batch than the
- *       overlapped fill and drain phases win.  The overlap pays only for INDEPENDENT batches on independent
- *       queues (rtlws_multi.h, shards per device: f32 0.66 -> 0.71); the option stays for callers who can
- *       measure their own case.  With Q > 1 an engine's launches must come from one thread at a time.
- * set: 0, -1 for an unknown name, -3 if the queues of "split" cannot be created.  get: the value ("cu_count" is
- * readable too), -2 if unknown.  An option must not be changed while another thread launches on the same engine
+ * (Removed in round 6: "split" = Q, a batch's rows as Q concurrent launches on engine-owned queues joined back
+ * into the caller's stream.  Measured slower than one launch at every Q -- 0.42 against 0.46 of the HBM roofline
+ * in f64 arithmetic, 0.54 against 0.65 in f32, profiles/r05_split_priority_queues.txt: the fork and the join are
+ * cross-queue dependencies that cost more than the overlapped fill and drain phases win.  The overlap pays only
+ * for INDEPENDENT batches on independent queues: rtlws_multi.h, shards per device.)
+ * set: 0, -1 for an unknown name.  get: the value ("cu_count" is readable too), -2 if unknown.  An option must not be changed while another thread launches on the same engine
  * (the launch paths read the options without the engine's lock). */
 int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value);
 int rtlws_engine_get_option(const rtlws_engine* e, const char* name);
@@ -322,6 +315,7 @@ int rtlws_copy_d2d(rtlws_engine* e, void* dst_dev, const void* src_dev, size_t b
 int rtlws_spectra_grid(rtlws_engine* e, const rtlws_spectra_desc* desc, long nframes,
                        int* blocks, int* threads, int* lds_bytes);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,12 @@ const char* rtlws_host_error(void);
 long rtlws_host_error_count(void);
 void rtlws_host_error_clear(void);
 
+/* For companion libraries built on the host layer (librtlws_cbb.so uses both): record a failure of an entry point
+ * that cannot return one -- sticky first message, counter, stderr for the first and every 1024th -- and the device
+ * index the drop-in entry points use ($RTLWS_DEVICE, read once; default 0). */
+void rtlws_host_fail(const char* where, const char* what);
+int rtlws_host_device(void);
+
 #ifdef __cplusplus
 }
 #endif

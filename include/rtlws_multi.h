@@ -60,7 +60,9 @@ int rtlws_multi_shards(const rtlws_multi* m);
 /* Why the last upload / run / download of `m` returned non-zero: "shard g (device d): <call>: <the HIP
  * shim's text>" of its first failing shard ("" after a success).  The failing call ran on a shard's own
  * thread, so the CALLER's rtlws_last_error() does not hold it.  m == NULL: the same for the last
- * rtlws_multi_open of this process that returned NULL. */
+ * rtlws_multi_open of the CALLING THREAD that returned NULL (per thread, like rtlws_last_error()).
+ * A handle is single-caller: upload / run / download / error / close of one rtlws_multi must come from one thread
+ * at a time (its shards share one command mailbox); different handles are independent. */
 const char* rtlws_multi_error(const rtlws_multi* m);
 /* Where shard g runs: its device's PCI bus id, NUMA node and cpuset as the shard thread found them
  * (rtlws_topo.h; unknown fields "" / -1 / 0) and the number of CPUs the thread pinned itself to

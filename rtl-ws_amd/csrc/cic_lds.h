@@ -18,9 +18,7 @@ namespace rtlws {
 
 // cache policy of the staging loads: 2 = nontemporal (streamed once; measured
 // +8-10 % over the default policy, tools/cic_fused_rates.py)
-#ifndef RTLWS_GLDS_AUX
 #define RTLWS_GLDS_AUX 2
-#endif
 
 // Issue the copy of one piece (128R bytes at s) to LDS at d (wave-uniform, 16-byte
 // aligned): 1 KiB pieces, 256-byte pieces and, for odd R, one 128-byte piece by
@@ -150,12 +148,9 @@ __device__ __forceinline__ void cic_copies4_ct(const uint8_t* g, uint8_t* d)    
     }
 }
 
-// -DRTLWS_CIC_TAIL_X4=1 (experiment): the sub-KiB tail of a piece (512 B at R = 12, 256 B at R = 10)
-// as ONE 16-byte-per-lane copy by the first 32 / 16 lanes instead of two / one 4-byte-per-lane
-// copies by all 64 -- fewer DMA instructions and 16-byte requests throughout.
-#ifndef RTLWS_CIC_TAIL_X4
-#define RTLWS_CIC_TAIL_X4 0
-#endif
+// (Measured and not kept, profiles/r03_ab_cic_tail_x4.txt: the sub-KiB tail of a piece as ONE 16-byte-per-lane
+// copy by the first 32 / 16 lanes instead of two / one 4-byte-per-lane copies by all 64;
+// tools/variants/csrc_hooks.patch restores the switch.)
 
 template <int RC>
 __device__ __forceinline__ void cic_piece_to_lds_ct(const uint8_t* s, uint8_t* d, int lane)
@@ -164,13 +159,7 @@ __device__ __forceinline__ void cic_piece_to_lds_ct(const uint8_t* s, uint8_t* d
     constexpr int n16 = chunk >> 10, n4 = (chunk & 1023) >> 8;
     static_assert((chunk & 255) == 0, "even factors only");
     cic_copies16_ct<0, 0, n16>(s + lane * 16, d);
-#if RTLWS_CIC_TAIL_X4
-    if constexpr (n4 > 0) {
-        if (lane < 16 * n4) cic_copies16_ct<n16 * 1024, 0, 1>(s + lane * 16, d);
-    }
-#else
     cic_copies4_ct<n16 * 1024, 0, n4>(s + lane * 4, d);
-#endif
 }
 
 }  // namespace rtlws

@@ -142,16 +142,10 @@ __device__ __forceinline__ void fft16_fma(f2 (&v)[16])
     { const f2 x2 = v[13]; v[13] = v[14]; v[14] = x2; }
 }
 
-#ifndef RTLWS_FFT16_FMA
-#define RTLWS_FFT16_FMA 1      // -DRTLWS_FFT16_FMA=0: the multiply-then-butterfly form, for the A/B
-#endif
+// (the multiply-then-butterfly form fft16() is the A/B partner: tools/variants/csrc_hooks.patch, -DRTLWS_FFT16_FMA=0)
 __device__ __forceinline__ void fft16_sel(f2 (&v)[16])
 {
-#if RTLWS_FFT16_FMA
     fft16_fma(v);
-#else
-    fft16(v);
-#endif
 }
 
 template <int R>

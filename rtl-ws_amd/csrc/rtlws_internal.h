@@ -26,9 +26,7 @@ constexpr int cic_ct_factor(int in_kind) { return in_kind == IN_CU8_CIC10 ? 10 :
 // N); a piece (64 samples) is 128R bytes.
 constexpr int CICR_LDS_WAVE_BYTES = 9216;
 // pieces in flight per round for the compile-time factors (8: measured +3 % over 4 at R = 12, N = 2048, although the 24 KiB of LDS per workgroup leave 3 wavefronts per SIMD instead of 4: bytes in flight matter more than wavefronts; -DRTLWS_CIC_CT_ROUND=4 for the A/B)
-#ifndef RTLWS_CIC_CT_ROUND
 #define RTLWS_CIC_CT_ROUND 8
-#endif
 constexpr int cicr_lds_round(int in_kind) { return in_kind >= IN_CU8_CIC10 ? RTLWS_CIC_CT_ROUND : in_kind == IN_CU8_CICR_LDS4 ? 4 : in_kind == IN_CU8_CICR_LDS2 ? 2 : 1; }
 // bytes of LDS one wavefront stages its round in
 constexpr int cic_stage_wave_bytes(int in_kind)
@@ -124,6 +122,7 @@ constexpr int f64_fused_lds_bytes(int n_fft) { return 16 * f64_fused_lds_elems(n
 constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
 // rectangular 1024-point cmplx_u8 frames: the one-transposition kernel (engine option f64_x1024)
 hipError_t launch_spectra_f64_1024x(const SpectraParamsF64&, int blocks, int waves, hipStream_t);
+size_t spectra_f64_1024x_lds_bytes(int waves);      // dynamic LDS per workgroup of that form (waves = 1 | 8)
 hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_2048(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
@@ -142,9 +141,7 @@ hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, i
 //     or accumulators and are built for 3.
 //   N = 4096: 3 (R3 = 16 twiddles and a bigger last pass).
 // RTLWS_WAVES_BIG overrides the "3" for experiments.
-#ifndef RTLWS_WAVES_BIG
 #define RTLWS_WAVES_BIG 3
-#endif
 // input kinds that get a dedicated K == 1 instantiation (no accumulators)
 constexpr bool fused_kone_kind(int in_kind)
 {
@@ -181,18 +178,14 @@ constexpr int fused_waves_per_simd(int n_fft, int in_kind, bool win, bool kone)
 // One-frame-ahead prefetch of the raw cmplx_u8 bytes (16 VGPRs).  Worth <= 2 % at
 // 12-16 resident wavefronts per CU; the windowed 4096-point kernels have no
 // room for it at 168 VGPRs, so they load in the loop instead of spilling.
-#ifndef RTLWS_PREFETCH_4096WIN
 #define RTLWS_PREFETCH_4096WIN 0
-#endif
 constexpr bool fused_prefetch_u8(int n_fft, bool win) { return RTLWS_PREFETCH_4096WIN || !(n_fft == 4096 && win); }
 
 // ... those kernels prefetch WITHOUT registers instead: the next frame's bytes are copied
 // into LDS by global_load_lds (LDS-DMA, two 1-KiB copies per wavefront and frame, double
 // buffered: 4*N bytes of LDS beside the transposition buffer) while the current frame is
 // transformed, and read back with sixteen ds_read_u16 per thread.  -DRTLWS_DMA_PF=0: off.
-#ifndef RTLWS_DMA_PF
 #define RTLWS_DMA_PF 1
-#endif
 constexpr bool fused_dma_prefetch(int n_fft, int in_kind, bool win)
 {
     return RTLWS_DMA_PF && in_kind == IN_CU8 && !fused_prefetch_u8(n_fft, win);
@@ -229,9 +222,7 @@ constexpr int v2_blocks_per_cu(int n_fft)
     return 163840 / v2_lds_bytes(n_fft) < 8 / (n_fft / 2048) ? 163840 / v2_lds_bytes(n_fft) : 8 / (n_fft / 2048);
 }
 // which descriptors take it (the shim may override with RTLWS_V2=0|1 for A/B runs)
-#ifndef RTLWS_V2_DEFAULT
 #define RTLWS_V2_DEFAULT 1
-#endif
 constexpr bool fused_v2_kind(int n_fft, int in_kind) { return (n_fft == 4096 || n_fft == 2048) && in_kind == IN_CU8; }
 hipError_t launch_spectra_fused_v2(const SpectraParams&, int blocks, hipStream_t);
 

@@ -77,11 +77,10 @@ struct EngineOpts {
     int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
     int f64_x1024 = 1;           // RTLWS_F64_X1024=0: rectangular 1024-point u8 frames stay on the two-transposition kernel
     int f64_x_waves = 0;         // RTLWS_F64_X_WAVES: wavefronts per workgroup of that kernel: 0 = by batch size, 1, 8
+    bool f64_x_waves8_ok = true; // the device's LDS limit per workgroup holds the eight-wavefront form (136 KiB)
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
     int cic_round = 0;           // RTLWS_CIC_ROUND=1|2|4: LDS staging depth where R fits it
-    int split = 1;               // RTLWS_SPLIT: a batch's rows as this many concurrent launches (engine-owned queues)
 };
-constexpr int kMaxSplit = 8;
 
 struct rtlws_engine {
     int device = 0;
@@ -90,13 +89,6 @@ struct rtlws_engine {
     EngineOpts opt;
     std::mutex mu;
     std::map<int, Tables> tables;   // by n_fft (fused) or -n_fft (direct)
-    // option "split": the side queues ranges 1 .. Q-1 of a batch are launched on, the event the caller's
-    // stream forks them at and the events it joins them with; created when the option is set (never on a
-    // launch path: a launch only enqueues, so it may be captured into a hipGraph)
-    hipStream_t split_q[kMaxSplit - 1] = {};
-    hipEvent_t split_fork = nullptr;
-    hipEvent_t split_join[kMaxSplit - 1] = {};
-    int split_ready = 0;            // side queues that exist
 };
 
 namespace {
@@ -369,60 +361,9 @@ int fused_blocks(const rtlws_engine* e, int n_fft, long ngroups, int in_kind = 0
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
-// option "split" = Q: make the Q - 1 side queues and the fork / join events exist (engine mutex held)
-int split_prepare(rtlws_engine* e, int q)
-{
-    if (q > kMaxSplit) q = kMaxSplit;
-    HIP_TRY(hipSetDevice(e->device), -3);
-    if (q > 1 && !e->split_fork) HIP_TRY(hipEventCreateWithFlags(&e->split_fork, hipEventDisableTiming), -3);
-    // The side queues are created at the HIGHEST stream priority: HIP multiplexes the streams of one priority
-    // over a few hardware queues (4 by default), and a side queue that shares a hardware queue with the stream it
-    // waits for (or that waits for it) stalls for milliseconds (profiles/r05_split_option_and_large_launches.txt:
-    // 14 ms per batch with five normal-priority streams in the process); priority classes have hardware queues
-    // of their own.
-    int prio_low = 0, prio_high = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;
-    while (e->split_ready < q - 1) {
-        const int i = e->split_ready;
-        HIP_TRY(hipStreamCreateWithPriority(&e->split_q[i], hipStreamNonBlocking, prio_high), -3);
-        HIP_TRY(hipEventCreateWithFlags(&e->split_join[i], hipEventDisableTiming), -3);
-        e->split_ready = i + 1;
-    }
-    return 0;
-}
-
-// How many concurrent launches a batch of `rows` output rows is cut into: the option, but never ranges of
-// fewer than two rows per resident wavefront slot (a short range is all fill and drain).
-int split_count(const rtlws_engine* e, long rows)
-{
-    int q = e->opt.split;
-    if (q > e->split_ready + 1) q = e->split_ready + 1;
-    while (q > 1 && rows / q < 16L * e->cu_count) --q;
-    return q < 1 ? 1 : q;
-}
-
-// Range r of Q: rows [r * rows / Q, (r + 1) * rows / Q) -- contiguous, whole K-groups (a row IS a K-group),
-// balanced to one row.  Range 0 runs on the caller's stream `st`, ranges 1 .. Q-1 on the engine's side
-// queues, forked from `st` by an event and joined back into it by one event each: to the caller the batch
-// is still ordered on `st` alone.  launch(r, row0, nrows, stream) enqueues one range.
 // hipStreamWaitEvent dereferences its stream argument: the hipStreamLegacy token ((hipStream_t)1) crashes it
 // (ROCm 7.2).  This library is built with the legacy default-stream semantics, where stream 0 IS that stream.
 hipStream_t waitable(hipStream_t st) { return st == hipStreamLegacy ? nullptr : st; }
-
-template <class F>
-hipError_t split_launch(rtlws_engine* e, hipStream_t st, int Q, long rows, F&& launch)
-{
-    hipError_t err = hipEventRecord(e->split_fork, waitable(st));
-    for (int r = 1; r < Q && err == hipSuccess; ++r) {
-        const long r0 = r * rows / Q, r1 = (r + 1) * rows / Q;
-        err = hipStreamWaitEvent(e->split_q[r - 1], e->split_fork, 0);
-        if (err == hipSuccess) err = launch(r, r0, r1 - r0, e->split_q[r - 1]);
-        if (err == hipSuccess) err = hipEventRecord(e->split_join[r - 1], e->split_q[r - 1]);
-    }
-    if (err == hipSuccess) err = launch(0, 0L, rows / Q, st);
-    for (int r = 1; r < Q && err == hipSuccess; ++r) err = hipStreamWaitEvent(waitable(st), e->split_join[r - 1], 0);
-    return err;
-}
 
 }  // namespace
 
@@ -473,17 +414,16 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.f64_x_waves = env_int("RTLWS_F64_X_WAVES", 0);
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
-    e->opt.split = env_int("RTLWS_SPLIT", 1);
-    if (e->opt.split < 1) e->opt.split = 1;
-    if (e->opt.split > kMaxSplit) e->opt.split = kMaxSplit;
+    // the eight-wavefront workgroups of spectrum_f64_1024x.hip need 136 KiB of LDS: where the device cannot give
+    // a workgroup that much, large batches keep the one-wavefront form (17 KiB) instead of failing
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess ||
+        (size_t)lds_max < rtlws::spectra_f64_1024x_lds_bytes(8))
+        e->opt.f64_x_waves8_ok = false;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_err("hipStreamCreate", err);
         delete e;
-        return nullptr;
-    }
-    if (e->opt.split > 1 && split_prepare(e, e->opt.split) != 0) {
-        rtlws_engine_destroy(e);
         return nullptr;
     }
     return e;
@@ -495,12 +435,6 @@ void rtlws_engine_destroy(rtlws_engine* e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->tables) free_tables(kv.second);
-    for (int i = 0; i < e->split_ready; ++i) {
-        (void)hipStreamSynchronize(e->split_q[i]);
-        (void)hipStreamDestroy(e->split_q[i]);
-        (void)hipEventDestroy(e->split_join[i]);
-    }
-    if (e->split_fork) (void)hipEventDestroy(e->split_fork);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -518,14 +452,9 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
-    else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8 || value == 12) ? value : 0;
+    else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
-    else if (k == "split") {
-        const int q = value < 1 ? 1 : (value > kMaxSplit ? kMaxSplit : value);
-        if (split_prepare(e, q) != 0) return -3;
-        e->opt.split = q;
-    }
     else {
         g_err = "rtlws_engine_set_option: unknown option '" + k + "'";
         return -1;
@@ -545,7 +474,6 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
     if (k == "f64_x_waves") return e->opt.f64_x_waves;
     if (k == "cic_direct") return e->opt.cic_direct;
     if (k == "cic_round") return e->opt.cic_round;
-    if (k == "split") return e->opt.split;
     if (k == "cu_count") return e->cu_count;
     return -2;
 }
@@ -596,7 +524,7 @@ int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft)
                 p.rows_f32 = rows_f32 && out != rtlws::OUT_PAYLOAD;
                 if (n_fft == 1024 && (out == rtlws::OUT_SUM || k_avg == 1)) {
                     p.window = nullptr;
-                    err = rtlws::launch_spectra_f64_1024x(p, 0, 8, e->stream);
+                    if (e->opt.f64_x_waves8_ok) err = rtlws::launch_spectra_f64_1024x(p, 0, 8, e->stream);
                 }
                 if (n_fft == 4096)
                     for (int w = 0; w <= 1 && err == hipSuccess; ++w) {
@@ -886,23 +814,7 @@ int rtlws_spectra_batch(rtlws_engine* e, const rtlws_spectra_desc* d, const void
         // the direct kernel sums R bytes itself
         return rtlws::launch_spectra_direct(pp, in_kind >= rtlws::IN_CU8_CIC8 ? (int)rtlws::IN_CU8 : in_kind, s);
     };
-    hipError_t err;
-    const int Q = fused ? split_count(e, p.ngroups) : 1;
-    if (Q <= 1) {
-        err = launch(p, st);
-    } else {
-        // option "split": the rows as Q concurrent launches (their fill and drain phases overlap)
-        const size_t in_row = (size_t)d->k_avg * d->n_fft * p.cic_r *
-                              (d->input == RTLWS_IN_CU8 ? 2 : d->input == RTLWS_IN_CS32 ? 8 : 4);
-        const size_t out_row = (size_t)d->n_fft * (d->output == RTLWS_OUT_PAYLOAD_U8 ? 1 : 4);
-        err = split_launch(e, st, Q, p.ngroups, [&](int, long r0, long n, hipStream_t s) {
-            rtlws::SpectraParams pp = p;
-            pp.in = static_cast<const char*>(d_in) + r0 * in_row;
-            pp.out = static_cast<char*>(d_out) + r0 * out_row;
-            pp.ngroups = n;
-            return launch(pp, s);
-        });
-    }
+    const hipError_t err = launch(p, st);
     if (err != hipSuccess) {
         set_err("spectra kernel launch", err);
         return -3;
@@ -998,6 +910,7 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
             // wavefronts take the workgroup's rows one at a time (spectrum_f64_1024x.hip, WAVES)
             int waves = e->opt.f64_x_waves;
             if (waves == 0) waves = (pp.ngroups >= 32L * e->cu_count) ? 8 : 1;
+            if (!e->opt.f64_x_waves8_ok) waves = 1;
             if (waves >= 8) blocks = e->cu_count;
             return rtlws::launch_spectra_f64_1024x(pp, (int)blocks, waves, s);
         }
@@ -1007,22 +920,7 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
         default: return rtlws::launch_spectra_f64_fused_4096(pp, in_kind, (int)blocks, s, e->device);
         }
     };
-    hipError_t err;
-    const int Q = fused ? split_count(e, p.ngroups) : 1;
-    if (Q <= 1) {
-        err = launch(p, st);
-    } else {
-        const size_t in_row = (size_t)d->k_avg * d->n_fft * p.cic_r *
-                              (d->input == RTLWS_IN_CU8 ? 2 : d->input == RTLWS_IN_CS32 ? 8 : 4);
-        const size_t out_row = (size_t)d->n_fft * (d->output == RTLWS_OUT_PAYLOAD_U8 ? 1 : p.rows_f32 ? 4 : 8);
-        err = split_launch(e, st, Q, p.ngroups, [&](int, long r0, long n, hipStream_t s) {
-            rtlws::SpectraParamsF64 pp = p;
-            pp.in = static_cast<const char*>(d_in) + r0 * in_row;
-            pp.out = static_cast<char*>(d_out) + r0 * out_row;
-            pp.ngroups = n;
-            return launch(pp, s);
-        });
-    }
+    const hipError_t err = launch(p, st);
     if (err != hipSuccess) {
         set_err("f64 spectra kernel launch", err);
         return -3;

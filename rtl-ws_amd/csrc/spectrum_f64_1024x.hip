@@ -38,9 +38,7 @@
 #include "rtlws_internal.h"
 #include "fft_regs_f64.h"
 
-#ifndef RTLWS_X_LDS_ORDER
 #define RTLWS_X_LDS_ORDER 0
-#endif
 
 namespace rtlws {
 
@@ -77,17 +75,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     constexpr int N = 1024;
     static_assert(!(ROWF32 && OUT == OUT_PAYLOAD), "payload rows are bytes in either form");
     static_assert(WAVES == 1 || WAVES % 4 == 0, "whole wavefronts per SIMD");
-    static_assert(WAVES != 12 || (KONE && OUT == OUT_SUM), "the three-per-SIMD form exists for the measured case only");
     extern __shared__ __attribute__((aligned(16))) double2 lds_all[];
-    // WAVES = 12 (three wavefronts per SIMD; a measurement): <= 168 VGPRs and 160 KiB / 12 of LDS per
-    // wavefront -- the inner twiddles live in LDS ([slot][lane], 16 KiB, shared by the twelve) instead of 64 VGPRs,
-    // and the transposition goes through a 9 KiB slice in two 8-byte halves (re, then im; rows of 16 padded to 18
-    // doubles: 16-byte aligned ds_read_b128, conflict-free either way)
-    constexpr bool W12 = (WAVES == 12);
-    constexpr int SLICE_F2 = W12 ? (64 * 18) / 2 : 17 * 64;           // double2 elements per wavefront
-    double2* const twb_lds = lds_all;                                  // (W12) [16][64]
-    double2* const ldsd = lds_all + (W12 ? 1024 : 0) + (WAVES == 1 ? 0 : (threadIdx.x >> 6) * SLICE_F2);   // this wavefront's own slice
-    unsigned* const row_counter = reinterpret_cast<unsigned*>(lds_all + (W12 ? 1024 : 0) + WAVES * SLICE_F2);    // (WAVES > 1)
+    // (three wavefronts per SIMD -- WAVES = 12 at 164 VGPRs, inner twiddles and a two-halves transposition in LDS --
+    // was built and measured slower, profiles/r05_ab_three_wavefronts_per_simd.txt; tools/variants/csrc_hooks.patch)
+    constexpr int SLICE_F2 = 17 * 64;                                  // double2 elements per wavefront
+    double2* const ldsd = lds_all + (WAVES == 1 ? 0 : (threadIdx.x >> 6) * SLICE_F2);   // this wavefront's own slice
+    unsigned* const row_counter = reinterpret_cast<unsigned*>(lds_all + WAVES * SLICE_F2);    // (WAVES > 1)
 
     const int t = threadIdx.x & 63;
     const int K = KONE ? 1 : p.k_avg;
@@ -96,9 +89,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
     long g = (long)blockIdx.x + (WAVES == 1 ? 0L : (long)(threadIdx.x >> 6) * gridDim.x);
     if constexpr (WAVES > 1) {
         if (threadIdx.x == 0) *row_counter = WAVES;
-        if constexpr (WAVES == 12) {
-            for (int e = threadIdx.x; e < 1024; e += 64 * WAVES) twb_lds[(e & 15) * 64 + (e >> 4)] = p.twxb[e];   // [lane][slot] -> [slot][lane]
-        }
         __syncthreads();                                        // the only barrier of the kernel
     }
     // the row after `cur`: WAVES = 1 strides, WAVES > 1 takes the workgroup's next undone row (lane 0's LDS
@@ -112,39 +102,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             return (long)blockIdx.x + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)v) * gridDim.x;
         }
     };
-#ifdef RTLWS_X_STAMP     // diagnostic build (tools/r5_wave_timeline.py): per-wavefront stamps in the head of its last row
-    const unsigned long long stamp_real0 = wall_clock64(), stamp_clk0 = clock64();
-    long stamp_row = -1;
-    unsigned long long stamp_rows = 0;
-#endif
 
     unsigned raw[16];
     auto load_raw = [&](long frame) {
-#ifdef RTLWS_F64_ABL_NOLOAD      // timing-only build: no HBM reads
-#pragma unroll
-        for (int j = 0; j < 16; ++j) raw[j] = (unsigned)((frame * 131 + 64 * j + t) * 2654435761u >> 16) & 0xffffu;
-#else
         const uint16_t* src = reinterpret_cast<const uint16_t*>(p.in) + frame * N;
 #pragma unroll
         for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j + t);
-#endif
     };
     if (g < ngroups) load_raw(g * K);
 
     // lane constants, resident for the life of the (persistent) workgroup
-    f2 twA[8], twB[W12 ? 1 : 16];
+    f2 twA[8], twB[16];
 #pragma unroll
     for (int m = 0; m < 8; ++m) twA[m] = p.twxa[(t >> 4) * 8 + m];
-    if constexpr (!W12) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) twB[s] = p.twxb[t * 16 + s];
-    }
+    for (int s = 0; s < 16; ++s) twB[s] = p.twxb[t * 16 + s];
 #pragma unroll
     for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(twA[m].x), "v"(twA[m].y));      // retired before the loop
-    if constexpr (!W12) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) asm volatile("" ::"v"(twB[s].x), "v"(twB[s].y));
-    }
+    for (int s = 0; s < 16; ++s) asm volatile("" ::"v"(twB[s].x), "v"(twB[s].y));
 
     const int wp = t >> 4, wc = t & 15;         // writer side of the transposition: lane (p, c)
 
@@ -163,10 +139,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             // no: it reaches exactly X[0] (a constant sequence has a single non-zero bin), which is
             // never output (src/spectrum.c:31); it is kept, as in the other kernels.
             unsigned y[16];                     // y[4 b + pp]
-#ifdef RTLWS_F64_ABL_NOPASS0      // (energy-attribution build: no integer radix-4)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = raw[r];
-#else
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 pk_i16 x[4];
@@ -183,7 +155,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                 y[4 * b + 2] = __builtin_bit_cast(unsigned, (pk_i16)(s0 - s2));
                 y[4 * b + 3] = __builtin_bit_cast(unsigned, (pk_i16)(s1 - rot));
             }
-#endif
             {
                 long nf = frame + 1;
                 if (kf + 1 == K) nf = g_next * K;
@@ -194,7 +165,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
 
             // ---- cross-row 4 x 4 transpose (lane row <-> p): afterwards lane (row p, column c)
             // holds y_p[c + 16 (4 b + g)] in y[4 b + g]
-#ifndef RTLWS_F64_ABL_NOSWAP      // (energy-attribution build: no cross-row transpose)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 swap_rows16(y[4 * b + 0], y[4 * b + 1]);
@@ -202,70 +172,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                 swap_rows32(y[4 * b + 0], y[4 * b + 2]);
                 swap_rows32(y[4 * b + 1], y[4 * b + 3]);
             }
-#endif
             f2 v[16];
-#ifdef RTLWS_F64_ABL_NOCVT        // (energy-attribution build: the sample bits pasted into doubles near 1, no conversion)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                v[r] = mk(__hiloint2double(0x3ff00000, (int)y[r]), __hiloint2double(0x3ff80000, (int)y[r]));
-#else
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 v[r] = mk((double)(short)(y[r] & 0xffffu), (double)((int)y[r] >> 16));
-#endif
 
             // ---- pass A: radix-16 over r with the geometric pre-twiddle (W_64^p)^r absorbed;
             // slot s holds index q = rev16(s)
-#ifndef RTLWS_F64_ABL_NOPASSA     // (energy-attribution builds, tools/r5_energy_abl.sh: wrong results, same data flow)
             fft_last<16>(v, 0, twA);
-#endif
             // inner twiddles W_256^(c q) x the lane constant W_1024^(p c) x 1/128
-#ifndef RTLWS_F64_ABL_NOTWB
-            if constexpr (W12) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twb_lds[s * 64 + t]);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twB[s]);
-            }
-#else
-#pragma unroll
-            for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(v[s].x), "+v"(v[s].y));
-#endif
+            for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], twB[s]);
 
             // ---- the one transposition: (p, c; q) -> lane 4 q + p, sixteen c contiguous (rows
             // padded 16 -> 17 double2: conflict-free ds_write_b128 and ds_read_b128)
-#ifndef RTLWS_F64_ABL_NOLDS      // (timing-only build without the LDS traffic)
             // the slice is this wavefront's own: ordering within the wavefront only, never an s_barrier.
-            // RTLWS_X_LDS_ORDER 0: wavefront-scope fences (the compiler may spread the writes over pass A's
-            // tail and start pass B under the reads); 2: workgroup-scope fences, i.e. what __syncthreads() is
-            // around its s_barrier -- writes retired (lgkmcnt(0)) before the reads are issued
-            if constexpr (W12) {
-                double* const half = reinterpret_cast<double*>(ldsd);       // 64 rows of 18 doubles
-#pragma unroll
-                for (int part = 0; part < 2; ++part) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) half[18 * (4 * rev16(s) + wp) + wc] = part ? v[s].y : v[s].x;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                    for (int c = 0; c < 16; c += 2) {
-                        const double2 two = *reinterpret_cast<const double2*>(half + 18 * t + c);
-                        if (part) { v[c].y = two.x; v[c + 1].y = two.y; }
-                        else { v[c].x = two.x; v[c + 1].x = two.y; }
-                    }
-                }
-            } else {
-#if RTLWS_X_LDS_ORDER == 2
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#pragma unroll
-            for (int s = 0; s < 16; ++s) ldsd[17 * (4 * rev16(s) + wp) + wc] = v[s];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
+            // Wavefront-scope fences: the compiler may spread the writes over pass A's tail and start pass B
+            // under the reads.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -273,16 +196,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
 #pragma unroll
             for (int c = 0; c < 16; ++c) v[c] = ldsd[17 * t + c];
-            }
-#endif
 
             // ---- pass B: radix-16 over c; slot s holds q' = rev16(s): bin k = 64 q' + t
-#ifndef RTLWS_F64_ABL_NOPASSB
             fft16_sel(v);
-#endif
 
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -291,12 +209,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                     acc[u] = KONE ? pw : acc[u] + pw;
                     wdc = KONE ? pw : fma((double)(K - kf), pw, wdc);
                 } else if constexpr (KONE) {
-#ifdef RTLWS_F64_ABL_NOPOW       // (energy-attribution build: no |X|^2)
-                    acc[u] = v[u].x;
-                    asm volatile("" ::"v"(v[u].y));
-#else
                     acc[u] = fma(v[u].y, v[u].y, v[u].x * v[u].x);
-#endif
                 } else {
                     acc[u] = fma(v[u].y, v[u].y, fma(v[u].x, v[u].x, acc[u]));
                 }
@@ -330,46 +243,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : WAVES / 4) void spectr
                     reinterpret_cast<uint8_t*>(p.out)[i] = (uint8_t)m;
                 } else {
                     const double o = (OUT == OUT_DB) ? 10.0 * log10(a / (double)p.count) : a;
-#ifdef RTLWS_F64_ABL_NOSTORE     // timing-only build: values kept live, nothing stored
-                    if (p.k_avg == 12345) reinterpret_cast<double*>(p.out)[i] = o;
-                    else asm volatile("" ::"v"(o));
-#else
                     if constexpr (ROWF32) __builtin_nontemporal_store((float)o, reinterpret_cast<float*>(p.out) + i);
                     else __builtin_nontemporal_store(o, reinterpret_cast<double*>(p.out) + i);
-#endif
                 }
             }
         }
-#ifdef RTLWS_X_STAMP
-        stamp_row = g;
-        ++stamp_rows;
-#endif
         g = g_next;
     }
-#ifdef RTLWS_X_STAMP
-    // {start, end (100 MHz), start, end (shader clocks), HW_ID, XCC_ID, rows, workgroup}; HW_ID: wave [3:0],
-    // SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
-    if (t == 0 && stamp_row >= 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.out) + stamp_row * N * (ROWF32 ? 4 : 8));
-        st[0] = stamp_real0;
-        st[1] = wall_clock64();
-        st[2] = stamp_clk0;
-        st[3] = clock64();
-        st[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        st[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        st[6] = stamp_rows;
-        st[7] = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    }
-#endif
 }
 
 // LDS: one 16 x 17 x 64-byte transposition slice per wavefront (+ the row counter)
-constexpr size_t x_lds_bytes(int waves)
-{
-    return waves == 12 ? (size_t)16384 + (size_t)waves * 64 * 18 * 8 + 16       // inner twiddles + twelve 9 KiB slices
-                       : (size_t)waves * 16 * 17 * 64 + (waves > 1 ? 16 : 0);
-}
+constexpr size_t x_lds_bytes(int waves) { return (size_t)waves * 16 * 17 * 64 + (waves > 1 ? 16 : 0); }
+size_t spectra_f64_1024x_lds_bytes(int waves) { return x_lds_bytes(waves >= 8 ? 8 : 1); }
 
 template <int OUT, bool ROWF32, int WAVES>
 static hipError_t launch_x_k(const SpectraParamsF64& p, int blocks, hipStream_t st)
@@ -411,31 +296,8 @@ static hipError_t launch_x_w(const SpectraParamsF64& p, int blocks, hipStream_t 
 }
 
 // waves = 1: `blocks` one-wavefront workgroups; waves = 8: `blocks` workgroups of eight wavefronts (one per CU)
-// (waves = 12: three wavefronts per SIMD, K = 1 power sums only -- the measurement of DESIGN.md 6.3; anything else
-// falls back to eight)
-static hipError_t launch_x_12(const SpectraParamsF64& p, int blocks, hipStream_t st)
-{
-    constexpr size_t lds_bytes = x_lds_bytes(12);
-    static std::atomic<bool> done[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!done[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, true, 12>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectra_f64_1024x<OUT_SUM, true, false, 12>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        done[dev].store(true, std::memory_order_release);
-    }
-    if (blocks <= 0) return hipSuccess;
-    if (p.rows_f32) hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, true, true, 12>), dim3(blocks), dim3(768), lds_bytes, st, p);
-    else hipLaunchKernelGGL((spectra_f64_1024x<OUT_SUM, true, false, 12>), dim3(blocks), dim3(768), lds_bytes, st, p);
-    return hipGetLastError();
-}
-
 hipError_t launch_spectra_f64_1024x(const SpectraParamsF64& p, int blocks, int waves, hipStream_t st)
 {
-    if (waves == 12 && p.k_avg == 1 && p.out_mode == OUT_SUM) return launch_x_12(p, blocks, st);
     return waves >= 8 ? launch_x_w<8>(p, blocks, st) : launch_x_w<1>(p, blocks, st);
 }
 

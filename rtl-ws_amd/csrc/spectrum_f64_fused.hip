@@ -72,14 +72,9 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
     // first frame's bytes first (sixteen 2-byte loads per lane, one 128-byte line per instruction)
     unsigned raw[16];
     auto load_raw = [&](long frame) {
-#ifdef RTLWS_F64_ABL_NOLOAD      // timing-only build: no HBM reads
-#pragma unroll
-        for (int r = 0; r < 16; ++r) raw[r] = (unsigned)((frame * 131 + T * r + t) * 2654435761u >> 16) & 0xffffu;
-#else
         const uint16_t* src = reinterpret_cast<const uint16_t*>(p.in) + frame * N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + T * r + t);
-#endif
     };
     if constexpr (IN == IN_CU8) {
         if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
@@ -163,7 +158,6 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
 #pragma unroll
             for (int s = 1; s < 16; ++s) v[s] = cmul(v[s], tw1[s]);
 
-#ifndef RTLWS_F64_ABL_NOLDS      // (timing-only build without the LDS traffic)
             __syncthreads();   // one wavefront per workgroup: no s_barrier, only the LDS ordering
 #pragma unroll
             for (int s = 0; s < 16; ++s) ldsd[rev16(s) * F64F_ROW + t] = v[s];
@@ -172,9 +166,7 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             // ---- pass 2: lane (q1, m2) holds y[q1][4*r2 + m2]
 #pragma unroll
             for (int r2 = 0; r2 < 16; ++r2) v[r2] = ldsd[q1 * F64F_ROW + R3 * r2 + m2];
-#endif
             fft16_sel(v);
-#ifndef RTLWS_F64_ABL_NOLDS
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -191,7 +183,6 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = ldsd[q1 * F64F_ROW + m2 * 17 + i];
-#endif
 #pragma unroll
             for (int j = 0; j < J; ++j) fft_last<R3>(v, j * R3, tw3);
 
@@ -305,16 +296,8 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
                 }
                 nt_d2* dst = reinterpret_cast<nt_d2*>(reinterpret_cast<double*>(p.out) + g * N + 256 * (s ^ (R3 / 2)));
                 const nt_d2 vx = {x[0], x[1]}, vy = {y[0], y[1]};
-#if defined(RTLWS_F64_ABL_NOSTORE)   // timing-only build: values kept live, nothing stored
-                if (p.k_avg == 12345) { dst[slot] = vx; dst[64 + slot] = vy; }
-                else asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
-#elif defined(RTLWS_F64_PLAIN_STORE)
-                dst[slot] = vx;
-                dst[64 + slot] = vy;
-#else
                 __builtin_nontemporal_store(vx, dst + slot);
                 __builtin_nontemporal_store(vy, dst + 64 + slot);
-#endif
             }
         } else {
             // N = 2048 / 4096: a lane owns 2 / 1 consecutive bins per s: every store instruction

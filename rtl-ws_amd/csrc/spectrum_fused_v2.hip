@@ -40,16 +40,10 @@
 
 namespace rtlws {
 
-#ifndef RTLWS_V2_PREFETCH
 #define RTLWS_V2_PREFETCH 1      // raw bytes of the next frame in flight during the transform
-#endif
-#ifndef RTLWS_V2_WINREGS
 #define RTLWS_V2_WINREGS 0       // 1: the 32 Hann weights of a lane live in registers (12 VGPRs spill with K > 1
                                  // and the prefetch); 0: regenerated per frame from 4 lane constants (236 VGPRs)
-#endif
-#ifndef RTLWS_V2_NT_STORE
 #define RTLWS_V2_NT_STORE 1      // nontemporal float2 stores: +2.5..3.5 % (rows are written once, never re-read)
-#endif
 
 constexpr int V2_P2 = 18;        // transposition 2: padded group of 16
 constexpr int v2_s1(int n_fft) { return n_fft / 16 + n_fft / 256; }      // transposition 1 row stride (T + R3)
@@ -298,21 +292,13 @@ __global__ __launch_bounds__(N / 32, 2) void spectra_fused_v2(const SpectraParam
             } else {
                 float* dst = reinterpret_cast<float*>(p.out) + g * N + i0;
                 if constexpr (J == 2) {
-#if RTLWS_V2_NT_STORE
                     typedef float nt_f4 __attribute__((ext_vector_type(4)));
                     const nt_f4 ov = {o[0], o[1], o[2], o[3]};
                     __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(dst));
-#else
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-#endif
                 } else {
-#if RTLWS_V2_NT_STORE
                     typedef float nt_f2 __attribute__((ext_vector_type(2)));
                     const nt_f2 ov = {o[0], o[1]};
                     __builtin_nontemporal_store(ov, reinterpret_cast<nt_f2*>(dst));
-#else
-                    *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
-#endif
                 }
             }
         }

@@ -20,6 +20,7 @@
  * ones in synth_sensor.c / synth_signal_source.c.
  */
 #include "cbb_main.h"
+#include "rtlws_cbb.h"
 
 #include <pthread.h>
 #include <stdio.h>

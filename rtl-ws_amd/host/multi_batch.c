@@ -62,8 +62,8 @@ struct rtlws_multi {
 };
 
 /* the text of the last failed rtlws_multi_open (there is no handle to keep it in) */
-static pthread_mutex_t g_open_mu = PTHREAD_MUTEX_INITIALIZER;
-static char g_open_err[352];
+/* why the calling thread's last rtlws_multi_open failed: per thread, like rtlws_last_error() */
+static __thread char g_open_err[352];
 
 int rtlws_multi_partition(long nframes, int k_avg, int shards, int g, long* first_frame, long* frame_count)
 {
@@ -321,10 +321,8 @@ rtlws_multi* rtlws_multi_open(int n_shards, const int* device_ids, const rtlws_s
     }
     /* every shard pins itself and builds its own engine, buffers and tables, concurrently */
     if (started < n_shards || post(m, started, CMD_INIT, 0, NULL, NULL) != 0) {
-        pthread_mutex_lock(&g_open_mu);
         if (started < n_shards) snprintf(g_open_err, sizeof g_open_err, "rtlws_multi_open: could not create %d threads", n_shards);
         else snprintf(g_open_err, sizeof g_open_err, "rtlws_multi_open: %s", m->err);
-        pthread_mutex_unlock(&g_open_mu);
         m->n = started;                                  /* only these have a thread to tell */
         rtlws_multi_close(m);
         return NULL;

@@ -3,6 +3,7 @@
 #include "rtlws_topo.h"
 
 #include <ctype.h>
+#include <errno.h>
 #include <pthread.h>
 #include <sched.h>
 #include <stdio.h>
@@ -36,19 +37,25 @@ int rtlws_topo_parse_cpulist(const char* list, unsigned char* cpus, int max)
         while (*p == ' ' || *p == ',') ++p;
         if (!*p) break;
         if (!isdigit((unsigned char)*p)) return -1;
+        errno = 0;
         a = strtol(p, &end, 10);
+        if (errno == ERANGE) return -1;
         b = a;
         p = end;
         if (*p == '-') {
             ++p;
             if (!isdigit((unsigned char)*p)) return -1;
             b = strtol(p, &end, 10);
+            if (errno == ERANGE) return -1;
             p = end;
         }
         if (b < a) return -1;
         if (*p && *p != ',' && *p != ' ' && *p != '\n') return -1;
+        /* CPUs from `max` on are not representable: ignored, never iterated over (a list such as
+         * "0-9223372036854775807" from a corrupt or caller-supplied sysfs tree must not spin) */
+        if (b >= max) b = (long)max - 1;
         for (; a <= b; ++a)
-            if (a < max && !cpus[a]) { cpus[a] = 1; ++count; }
+            if (!cpus[a]) { cpus[a] = 1; ++count; }
     }
     return count;
 }

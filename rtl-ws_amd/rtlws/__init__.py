@@ -98,10 +98,12 @@ MULTI_SYMBOLS = ["rtlws_multi_partition", "rtlws_multi_open", "rtlws_multi_shard
 TOPO_SYMBOLS = ["rtlws_topo_describe", "rtlws_topo_parse_cpulist", "rtlws_topo_pin_thread"]
 
 # include/rtlws_host.h: sticky failure record of the void entry points (librtlws_amd.so)
-HOST_SYMBOLS = ["rtlws_host_error", "rtlws_host_error_count", "rtlws_host_error_clear"]
+HOST_SYMBOLS = ["rtlws_host_error", "rtlws_host_error_count", "rtlws_host_error_clear", "rtlws_host_fail",
+                "rtlws_host_device"]
 
 CBB_SYMBOLS = ["cbb_init", "cbb_rf_decimator", "cbb_get_rtl_dev", "cbb_new_spectrum_available",
-               "cbb_get_spectrum_payload", "cbb_close"]
+               "cbb_get_spectrum_payload", "cbb_close",
+               "rtlws_cbb_published_frames", "rtlws_cbb_samples_seen"]      # include/rtlws_cbb.h
 SYNTH_SYMBOLS = ["rtl_init", "rtl_set_frequency", "rtl_set_sample_rate", "rtl_set_gain", "rtl_freq",
                  "rtl_sample_rate", "rtl_gain", "rtl_read_async", "rtl_cancel", "rtl_close",
                  "signal_source_start", "signal_source_add_callback",

@@ -25,35 +25,92 @@ def _declared_functions(header):
     return [n for n in names if n not in ("defined", "sizeof")]
 
 
+# which headers each library implements -- and, since round 6, ALL it exports
+LIB_HEADERS = {
+    "HIP_LIB": ("rtlws_hip.h",),
+    "AMD_LIB": ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h", "audio_main.h", "rtlws_host.h",
+                "rtlws_multi.h", "rtlws_topo.h"),
+    "CBB_LIB": ("cbb_main.h", "rtlws_cbb.h"),
+    "SYNTH_LIB": ("rtl_sensor.h", "signal_source.h"),
+}
+
+
+def _declared_by_lib():
+    out = {}
+    for lib, headers in LIB_HEADERS.items():
+        names = []
+        for h in headers:
+            fns = _declared_functions(h)
+            assert fns, h
+            names += fns
+        out[lib] = names
+    return out
+
+
+def _exported(path):
+    """Defined dynamic symbols of a shared object (nm -D --defined-only)."""
+    import subprocess
+    txt = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1].split("@")[0] for ln in txt.splitlines() if ln.strip()}
+
+
 def test_every_declared_symbol_is_exported(built):
     hip = ctypes.CDLL(built.HIP_LIB, mode=ctypes.RTLD_GLOBAL)
     amd = ctypes.CDLL(built.AMD_LIB)
-    declared_hip = _declared_functions("rtlws_hip.h")
-    assert len(declared_hip) >= 20
-    for name in declared_hip:
+    declared = _declared_by_lib()
+    assert len(declared["HIP_LIB"]) >= 20
+    for name in declared["HIP_LIB"]:
         assert hasattr(hip, name), "librtlws_hip.so lacks " + name
-    declared_amd = []
-    for h in ("spectrum.h", "resample.h", "rf_decimator.h", "rtlws_stream.h", "audio_main.h", "rtlws_host.h", "rtlws_multi.h"):
-        fns = _declared_functions(h)
-        assert fns, h
-        declared_amd += fns
-    for name in declared_amd:
+    for name in declared["AMD_LIB"]:
         assert hasattr(amd, name), "librtlws_amd.so lacks " + name
     # boundary #2 and the synthetic seam live in their own libraries
     synth = ctypes.CDLL(built.SYNTH_LIB, mode=ctypes.RTLD_GLOBAL)
     cbb = ctypes.CDLL(built.CBB_LIB)
-    declared_cbb = _declared_functions("cbb_main.h")
-    declared_synth = _declared_functions("rtl_sensor.h") + _declared_functions("signal_source.h")
-    for name in declared_cbb:
+    for name in declared["CBB_LIB"]:
         assert hasattr(cbb, name), "librtlws_cbb.so lacks " + name
-    for name in declared_synth:
+    for name in declared["SYNTH_LIB"]:
         assert hasattr(synth, name), "librtlws_synth.so lacks " + name
     # the binding's own lists agree with the headers
-    assert set(built.HIP_SYMBOLS) == set(declared_hip)
+    assert set(built.HIP_SYMBOLS) == set(declared["HIP_LIB"])
     assert (set(built.AMD_SYMBOLS) | set(built.STREAM_SYMBOLS) | set(built.AUDIO_SYMBOLS) | set(built.HOST_SYMBOLS)
-            | set(built.MULTI_SYMBOLS) == set(declared_amd))
-    assert set(built.CBB_SYMBOLS) == set(declared_cbb)
-    assert set(built.SYNTH_SYMBOLS) == set(declared_synth)
+            | set(built.MULTI_SYMBOLS) | set(built.TOPO_SYMBOLS) == set(declared["AMD_LIB"]))
+    assert set(built.CBB_SYMBOLS) == set(declared["CBB_LIB"])
+    assert set(built.SYNTH_SYMBOLS) == set(declared["SYNTH_LIB"])
+
+
+def test_every_exported_symbol_is_declared(built):
+    """The converse: a library a C server links exports its headers and NOTHING else -- no
+    kernel stubs, launchers, std:: instantiations or cross-file helpers (librtlws_hip.so used to leak 1 360 of
+    them).  -fvisibility=hidden + the version scripts of rtl-ws_amd/exports/."""
+    declared = _declared_by_lib()
+    for lib, names in declared.items():
+        got = _exported(getattr(built, lib))
+        assert got == set(names), "%s: exported but not declared %s; declared but not exported %s" % (
+            lib, sorted(got - set(names)), sorted(set(names) - got))
+    assert len(_exported(built.HIP_LIB)) == len(built.HIP_SYMBOLS)
+
+
+def test_hooks_patch_applies():
+    """tools/variants/csrc_hooks.patch (the measurement hooks, kept OUT of the product sources) still applies to
+    rtl-ws_amd/csrc, and the product sources carry none of its switches."""
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "rtl-ws_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "csrc")
+        shutil.copytree(src, dst)
+        r = subprocess.run(["patch", "-s", "-p3", "--dry-run", "-i", os.path.join(ROOT, "tools", "variants", "csrc_hooks.patch")],
+                           cwd=dst, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for f in os.listdir(src):
+        txt = open(os.path.join(src, f)).read()
+        for sw in ("RTLWS_F64_ABL_", "RTLWS_ABL_", "RTLWS_X_STAMP", "RTLWS_STAMP", "RTLWS_NO_NT", "RTLWS_F64_PLAIN_STORE"):
+            assert sw not in txt, "%s still carries %s" % (f, sw)
+        # no preprocessor conditional other than include guards and the per-size compile (-DRTLWS_N)
+        for m in re.finditer(r"^\s*#\s*(if|ifdef|ifndef|elif)\b(.*)$", txt, flags=re.M):
+            arg = m.group(2).strip()
+            assert arg.endswith("_H") or arg == "RTLWS_N", "%s: conditional on %r" % (f, arg)
 
 
 def test_abi_struct_layouts(built):

@@ -35,7 +35,11 @@ def test_workload_table_is_consistent():
     assert bench.parity_bounds_for("cic8_2048pt_f64")["max_rel_err_floor1e-9"] == 1e-10
     assert bench.parity_bounds_for("cic8_2048pt_f64c_f32o")["max_rel_err_floor1e-9"] <= 6e-8
     # every BASELINE.json configuration on the default line has the CPU path timed beside it
-    assert set(bench.EXTRA_CPU_BASELINE) == {"hann_4096pt_k8_db", "cic8_2048pt"} <= set(bench.EXTRA_WORKLOADS)
+    # ... in f32 AND in the reference's arithmetic: configs[2] and configs[3]
+    assert set(bench.EXTRA_CPU_BASELINE) == {"hann_4096pt_k8_db", "hann_4096pt_k8_db_f64c_f32o", "cic8_2048pt",
+                                             "cic8_2048pt_f64"} <= set(bench.EXTRA_WORKLOADS)
+    assert bench.precision_of("hann_4096pt_k8_db_f64c_f32o") == "f64c_f32o"
+    assert bench.algorithmic_bytes_per_frame(4096, 8, 0, "mean_db", f64=False) == 10240      # configs[2], f32 rows
 
 
 @pytest.mark.parametrize("name", ["batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic8_2048pt",
@@ -139,7 +143,7 @@ def test_headline_is_the_reference_arithmetic_workload():
     assert bench.algorithmic_bytes_per_frame(1024, 1, 0, "power_sum", f64=False) == 6144      # f32 rows
     assert bench.FAST_MODE in bench.EXTRA_WORKLOADS and bench.precision_of(bench.FAST_MODE) == "f32"
     assert bench.HEADLINE not in bench.EXTRA_WORKLOADS
-    assert all(n in bench.WORKLOADS and 2 <= q <= 8 for n, q in bench.EXTRA_SPLIT)
+    assert not hasattr(bench, "EXTRA_SPLIT")         # the "split" option was a measured loss: gone in round 6
     assert bench.parity_bounds_for(bench.HEADLINE)["max_rel_err_floor1e-9"] <= 6e-8
 
 
@@ -266,3 +270,35 @@ print("ok")
 """ % (ROOT, os.path.join(ROOT, "rtl-ws_amd"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_energy_counter_is_found_by_pci_bus_id():
+    """rocm_smi numbers every physical GPU and ignores HIP_VISIBLE_DEVICES, so the package
+    energy accumulator is looked up by the bus id HIP reports -- against a fake rsmi here: the third device matches,
+    a partition id in bits 28-31 does not matter, an unknown bus id gives None (the energy leg is dropped)."""
+    import ctypes as C
+    from rtlws import energy
+
+    class FakeSmi:
+        ids = [(0 << 32) | (0x05 << 8), (0 << 32) | (0x15 << 8), (3 << 28) | (0 << 32) | (0x65 << 8) | (0 << 3) | 0]
+
+        def rsmi_num_monitor_devices(self, n):
+            n._obj.value = len(self.ids)
+            return 0
+
+        def rsmi_dev_pci_id_get(self, i, out):
+            out._obj.value = self.ids[i.value]
+            return 0
+
+        def rsmi_dev_energy_count_get(self, i, cnt, res, ts):
+            cnt._obj.value, res._obj.value = 1000 * (i.value + 1), 15.3
+            return 0
+
+    assert energy.parse_bus_id("0000:0d:00.0") == (0, 0x0d, 0, 0) and energy.parse_bus_id("nonsense") is None
+    assert energy.bdf_fields((1 << 32) | (0x65 << 8) | (2 << 3) | 1) == (1, 0x65, 2, 1)
+    assert energy.rsmi_index_for_bus_id("0000:65:00.0", FakeSmi()) == 2
+    assert energy.rsmi_index_for_bus_id("0000:05:00.0", FakeSmi()) == 0
+    assert energy.rsmi_index_for_bus_id("0000:99:00.0", FakeSmi()) is None
+    ec = energy.EnergyCounter("0000:65:00.0", FakeSmi())
+    assert ec.index == 2 and abs(ec.joules() - 3000 * 15.3e-6) < 1e-9
+    assert energy.EnergyCounter("0000:99:00.0", FakeSmi()).joules() is None

@@ -65,20 +65,28 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
     assert runs[0]["parity"] == runs[1]["parity"]             # same seed, same kernel: identical statistics
 
 
-def test_run_workload_with_the_split_option(ctx, monkeypatch):
-    """bench.py --split Q: the batch's rows as Q concurrent launches (engine option "split"); the line says that
-    its event time is the batch's, the engine's option is restored, parity holds and the energy leg reports joules."""
+def test_energy_leg_and_box_calibration(ctx, monkeypatch):
+    """roofline.energy (the package energy accumulator of THIS device, found by PCI bus id -- ADVICE r5) and
+    roofline.box (a fixed v_fma_f64 stream at the cap: the chip's own figure)."""
     import bench
+    import rtlws
     monkeypatch.setattr(bench, "SETTLE_LAUNCHES", 40)
     monkeypatch.setattr(bench, "ENERGY_LAUNCHES", 200)
+    ec = bench.energy_counter_for(rtlws, 0)
+    ctx2 = dict(ctx, energy_counter=ec)
     for name in (bench.HEADLINE, bench.FAST_MODE):
-        r = bench.run_workload(ctx, name, steps=8, warmup=0, sets=2, frames_override=16384, split=2)
-        assert r["config"]["split"] == 2 and "concurrent launches" in r["roofline"]["frac_clock"]
+        r = bench.run_workload(ctx2, name, steps=8, warmup=0, sets=2, frames_override=16384)
         assert "failed" not in r["parity"] and bench.parity_failures(r["parity"], bench.parity_bounds_for(name)) == []
-        assert ctx["eng"].get_option("split") == 1
         en = r["roofline"].get("energy")
-        if en is not None:                    # (rocm_smi readable on the box)
+        if ec is not None:                    # (rocm_smi readable on the box)
             assert en["launches"] == 200 and 0.0 < en["mj_per_launch"] < 1000.0 and 100.0 < en["watts"] < 2000.0
+            assert en["bus_id"] == ec.bus_id and en["rsmi_index"] == ec.index
+    box = bench.box_calibration(rtlws, 0, ec, settle_s=0.05, measure_s=0.1)
+    assert box is not None and 1.0 < box["fma_f64_sclk_ghz_at_cap"] < 2.6
+    assert 3.5 < box["cycles_per_instruction_and_simd"] < 6.0          # v_fma_f64: 4 cycles per wave64 instruction
+    assert 20.0 < box["fma_f64_tflops"] < 90.0
+    if ec is not None:
+        assert 300.0 < box["watts"] < 2000.0
 
 
 def test_run_workload_uniform_input_variant(ctx):

@@ -117,20 +117,3 @@ def test_x1024_eight_wavefront_db_and_payload_rows(engine, oracle):
     ok = ref > 1e-9 * ref.max(axis=1, keepdims=True)
     assert np.abs(db - 10 * np.log10(ref))[ok].max() <= 1e-9
     assert np.array_equal(pay, np.stack([oracle.spectrum_payload(r, 1, 15) for r in ref]))
-
-
-@pytest.mark.parametrize("rows", [5, 3000, 9001])
-@pytest.mark.parametrize("rows_f32", [False, True])
-def test_x1024_three_wavefronts_per_simd_form(engine, oracle, rows, rows_f32):
-    """WAVES = 12 (engine option f64_x_waves = 12; K = 1 power sums): the measurement build of DESIGN.md 6.3 -- inner
-    twiddles read from LDS, the transposition in two 8-byte halves, <= 168 VGPRs -- computes the same transform in the
-    same operation order: rows bit-identical to the eight-wavefront form, and within the bounds against the oracle."""
-    from rtlws import synth
-    iq = synth.tone_noise_iq(rows, 1024, seed=1200 + rows)
-    with engine.option("f64_x_waves", 12):
-        got = engine.spectra(iq, 1024, f64=True, rows_f32=rows_f32)
-    with engine.option("f64_x_waves", 8):
-        ref8 = engine.spectra(iq, 1024, f64=True, rows_f32=rows_f32)
-    assert np.array_equal(got, ref8)
-    ref = oracle.batch_spectra_u8(iq, 1024, nthreads=8)
-    assert rel_err(got, ref, EPS_STRICT).max() <= (2.0 ** -24 * 1.001 if rows_f32 else STRICT_F64)

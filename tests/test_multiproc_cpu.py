@@ -92,6 +92,52 @@ def test_bench_gpus_n_fans_out_by_itself():
     assert 1.5 < own["all"][1] / own["all"][0] < 2.6
 
 
+def test_two_ranks_record_where_they_ran(tmp_path):
+    """every rank contributes device, PCI bus id, NUMA node, CPUs pinned and its own times to
+    per_rank.ranks, and rank 0 refuses an N-GPU line over ranks that share a device.  Two gloo ranks on a fake
+    sysfs tree (include/rtlws_topo.h takes the root as a parameter): two devices on two nodes whose CPUs are this
+    job's own, so that the pinning really happens.  Unmeasured on hardware -- this is the code path, on CPU."""
+    from test_topo_cpu import make_sysfs
+    cpus = sorted(os.sched_getaffinity(0))
+    lo, hi = cpus[:max(1, len(cpus) // 2)], cpus[max(1, len(cpus) // 2):] or cpus[:1]
+    as_list = lambda c: ",".join(str(x) for x in c)
+    buses = ["0000:05:00.0", "0000:85:00.0"]
+    root = make_sysfs(tmp_path / "sys", {buses[0]: 0, buses[1]: 1}, {0: as_list(lo), 1: as_list(hi)})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RTLWS_BENCH_BUS_IDS=",".join(buses), RTLWS_BENCH_SYSFS_ROOT=root)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--plumbing-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    ranks = res["per_rank"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["local_rank"] for r in ranks] == [0, 1]
+    assert [r["bus_id"] for r in ranks] == buses and [r["numa_node"] for r in ranks] == [0, 1]
+    assert [r["cpus_pinned"] for r in ranks] == [len(lo), len(hi)]
+    assert all(r["host"] and r["ms_per_step_own"] > 0 for r in ranks)
+    assert res["per_rank"]["device_clashes"] == []
+    # ... and two ranks on ONE device are refused: rank 0 exits 6 (torch.distributed.run turns any failing rank
+    # into its own non-zero code), the clash named in the line
+    env["RTLWS_BENCH_BUS_IDS"] = buses[0]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--plumbing-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["per_rank"]["device_clashes"] == [{"ranks": [0, 1], "host": ranks[0]["host"], "device": buses[0]}]
+
+
+def test_distinct_device_check_is_pure():
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = lambda r, host, bus, dev: {"rank": r, "host": host, "bus_id": bus, "device": dev}
+    eight = [rec(r, "n0", "0000:%02x:00.0" % (5 + 16 * r), r) for r in range(8)]
+    assert bench.check_distinct_devices(eight) == []
+    assert bench.check_distinct_devices(eight + [rec(8, "n1", eight[0]["bus_id"], 0)]) == []      # another host
+    bad = bench.check_distinct_devices(eight + [rec(8, "n0", eight[3]["bus_id"], 3)])
+    assert bad == [{"ranks": [3, 8], "host": "n0", "device": eight[3]["bus_id"]}]
+    assert bench.check_distinct_devices([rec(0, "n0", "", 0), rec(1, "n0", "", 0)]) != []          # no bus id: by index
+    assert bench.check_distinct_devices([rec(0, "n0", "", 0), rec(1, "n0", "", 0)], allow_shared=True) == []
+
+
 def test_bench_gpus_n_without_the_devices_fails_loudly():
     """More GPUs asked for than the host has: non-zero exit and no result line --
     never a silent n_gpus=1 under the name of an N-GPU run."""

@@ -37,6 +37,12 @@ def test_cpulist_parser(built):
     assert L.rtlws_topo_parse_cpulist(b"", buf, 64) == 0
     for bad in (b"3-1", b"a", b"1-", b"1;2", b"-3"):
         assert L.rtlws_topo_parse_cpulist(bad, buf, 64) == -1, bad
+    # a huge range (a corrupt or caller-supplied sysfs file) is clamped, not iterated over; an
+    # unrepresentable number is malformed
+    assert L.rtlws_topo_parse_cpulist(b"0-9223372036854775807", buf, 64) == 64
+    assert L.rtlws_topo_parse_cpulist(b"70-9223372036854775807", buf, 64) == 0
+    assert L.rtlws_topo_parse_cpulist(b"0-99999999999999999999999", buf, 64) == -1
+    assert L.rtlws_topo_parse_cpulist(b"99999999999999999999999", buf, 64) == -1
 
 
 @pytest.mark.parametrize("ndev,nnodes", [(1, 1), (2, 1), (2, 2), (8, 1), (8, 2)])

@@ -4,7 +4,6 @@
 
 usage (GPU box): python3 tools/r5_energy.py [f64c_f32o|f64|f32] [launches]   (kernel switches: RTLWS_* / RTLWS_HIP_LIB)
 """
-import ctypes as C
 import os
 import sys
 import time
@@ -15,16 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "rtl-ws_amd"))
 import torch      # noqa: E402
 import rtlws      # noqa: E402
 
-smi = C.CDLL("/opt/rocm/lib/librocm_smi64.so")
-assert smi.rsmi_init(C.c_uint64(0)) == 0, "rsmi_init"
+from rtlws import energy      # noqa: E402
+
+# the accumulator of HIP device 0, found by its PCI bus id (rocm_smi ignores HIP_VISIBLE_DEVICES: ADVICE r5)
+_EC = energy.for_hip_device(rtlws, 0)
+assert _EC is not None, "no energy counter for device 0"
 
 
 def energy_j():
-    cnt, res, ts = C.c_uint64(0), C.c_float(0), C.c_uint64(0)
-    rc = smi.rsmi_dev_energy_count_get(C.c_uint32(0), C.byref(cnt), C.byref(res), C.byref(ts))
-    if rc != 0:
-        raise RuntimeError("rsmi_dev_energy_count_get: %d" % rc)
-    return cnt.value * res.value * 1e-6
+    return _EC.joules()
 
 
 def main():

@@ -80,10 +80,20 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
         if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
     }
 
-    // the last pass's (cos, tan) pairs stay in registers, except in the one instantiation whose
-    // budget they break (4096-point, window, K-frame accumulators: 32 VGPRs of pairs): there
-    // they are re-read from the (L2-resident, 2 KiB) table every frame, under the LDS reads
+    // the last pass's (cos, tan) pairs stay in registers, except in the one instantiation family whose
+    // budget they break (4096-point, window, K-frame accumulators: 32 VGPRs of pairs): there the
+    // workgroup copies the 2 KiB table into LDS once, behind the transposition buffer, and every frame
+    // re-reads its eight pairs from there with the pass-3 LDS reads.  (Rounds 3-5 re-read them from the
+    // L2-resident table in global memory through a laundered pointer, which compiled to FLAT loads: they
+    // count on vmcnt AND lgkmcnt, so every wait for an LDS read also waited for an L2 round trip -- five
+    // exposed round trips per frame, 230 us per 16 384 frames where 150 were due;
+    // profiles/r06_f64_4096_tw3_from_lds.txt.)
     constexpr bool TW3_REGS = f64_fused_tw3_regs(N, IN, WIN, KONE);
+    double2* const tw3_lds = ldsd + f64_fused_lds_elems(N);       // (!TW3_REGS) [16][R3/2] pairs
+    if constexpr (!TW3_REGS) {
+        for (int e = threadIdx.x; e < 16 * (R3 / 2); e += T) tw3_lds[e] = p.tw2f[e];
+        __syncthreads();
+    }
     f2 tw1[16], tw3[R3 / 2];
 #pragma unroll
     for (int s = 0; s < 16; ++s) tw1[s] = p.tw1f[t * 16 + s];
@@ -176,10 +186,10 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             // ---- pass 3: lane (q2, g3) = (t / R3, t % R3): sixteen contiguous elements, J
             // twiddled radix-R3 butterflies in fused-multiply-add form
             if constexpr (!TW3_REGS) {
-                const double2* tp = p.tw2f + (t / R3) * (R3 / 2);
-                asm volatile("" : "+v"(tp));          // not hoisted out of the frame loop
+                int o = (t / R3) * (R3 / 2);
+                asm volatile("" : "+v"(o));           // not hoisted out of the frame loop (the registers are the point)
 #pragma unroll
-                for (int m = 0; m < R3 / 2; ++m) tw3[m] = tp[m];
+                for (int m = 0; m < R3 / 2; ++m) tw3[m] = tw3_lds[o + m];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = ldsd[q1 * F64F_ROW + m2 * 17 + i];
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
 template <int N, int IN, bool WIN, int OUT, bool KONE, bool ROWF32>
 static hipError_t launch_f64f_one(const SpectraParamsF64& p, int blocks, hipStream_t st, int device)
 {
-    constexpr size_t lds_bytes = f64_fused_lds_bytes(N);
+    constexpr size_t lds_bytes = f64_fused_lds_bytes(N) + (f64_fused_tw3_regs(N, IN, WIN, KONE) ? 0 : 16 * 16 * (N / 512));
     if constexpr (lds_bytes > 64 * 1024) {
         static std::atomic<unsigned long long> ready{0};
         const unsigned long long bit = 1ull << (device & 63);

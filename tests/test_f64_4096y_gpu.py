@@ -1,0 +1,93 @@
+"""spectrum_f64_4096y.hip -- windowed / K-frame 4096-point cmplx_u8 frames in the reference's arithmetic
+(src/spectrum.c:15-35,47-63 per frame, K loop of src/cbb_main.c:50-59, dB / payload epilogue of
+src/cbb_main.c:121-130) with ONE cross-wavefront exchange per frame and no twiddle multiplications -- against
+the f64 oracle under the STRICT metric (floor 1e-9 of the row maximum, bound 1e-10), against the kernel it
+replaces for these rows (spectrum_f64_fused.hip, engine option f64_y4096 = 0) and byte for byte on the payload.
+BASELINE configs[2] is this kernel's shape: Hann, K = 8, mean dB."""
+import numpy as np
+import pytest
+
+from helpers import rel_err, EPS_STRICT
+
+pytestmark = pytest.mark.gpu
+STRICT_F64 = 1e-10
+N = 4096
+
+
+def _window(synth, window):
+    return synth.hann(N) if window == "hann" else None
+
+
+@pytest.mark.parametrize("window,k_avg", [("hann", 1), ("hann", 2), ("hann", 8), ("rect", 2), ("rect", 3), ("rect", 8)])
+@pytest.mark.parametrize("rows_f32", [False, True])
+def test_y4096_vs_oracle_and_the_two_exchange_kernel(engine, oracle, window, k_avg, rows_f32):
+    from rtlws import synth
+    rows = 1030                       # more rows than resident workgroups (512): the row loop strides, ragged
+    iq = synth.tone_noise_iq(rows * k_avg, N, seed=400 + 7 * k_avg + (window == "hann"))
+    iq[3] = 128                       # a constant frame
+    iq[4] = synth.pure_tone_iq(1, N, seed=2)[0]
+    iq[5] = synth.uniform_iq(1, N, seed=2)[0]
+    assert engine.get_option("f64_y4096") == 1
+    got = engine.spectra(iq, N, k_avg=k_avg, window=window, f64=True, rows_f32=rows_f32)
+    assert got.shape == (rows, N) and got.dtype == (np.float32 if rows_f32 else np.float64)
+    ref = oracle.batch_spectra_u8(iq, N, K=k_avg, window=_window(synth, window), nthreads=8)
+    bound = 2.0 ** -24 * 1.001 if rows_f32 else STRICT_F64
+    assert rel_err(got, ref, EPS_STRICT).max() <= bound
+    with engine.option("f64_y4096", 0):
+        old = engine.spectra(iq[:40 * k_avg], N, k_avg=k_avg, window=window, f64=True, rows_f32=rows_f32)
+    assert rel_err(got[:40], old, EPS_STRICT).max() <= bound
+    assert engine.get_option("f64_y4096") == 1
+
+
+def test_y4096_dc_slot_weights(engine, oracle):
+    """Slot N/2 takes sum_k (K - k) P_k[N-1] (src/spectrum.c:25-33): bin N-1 lives on the last lane of the last
+    wavefront, slot N/2 on the first lane of the first."""
+    from rtlws import synth
+    for k_avg in (2, 6, 8):
+        iq = synth.uniform_iq(3 * k_avg, N, seed=k_avg)
+        got = engine.spectra(iq, N, k_avg=k_avg, f64=True)
+        ref = oracle.batch_spectra_u8(iq, N, K=k_avg)
+        assert rel_err(got, ref, EPS_STRICT).max() <= STRICT_F64
+        # closed form: slot i shows bin (i + N/2) % N, so bin N - 1 of frame k is slot N/2 - 1 of its K = 1 row
+        per_frame = oracle.batch_spectra_u8(iq[:k_avg], N, K=1)
+        want = sum((k_avg - k) * per_frame[k, N // 2 - 1] for k in range(k_avg))
+        assert abs(got[0, N // 2] - want) <= 1e-10 * ref[0].max()
+
+
+@pytest.mark.parametrize("rows_f32", [False, True])
+def test_y4096_mean_db_rows(engine, oracle, rows_f32):
+    """BASELINE configs[2]: Hann, K = 8, mean dB -- 10 log10(sum / K) in double, rounded once for f32 rows."""
+    from rtlws import synth
+    iq = synth.tone_noise_iq(8 * 520, N, seed=88)
+    ref = oracle.batch_spectra_u8(iq, N, K=8, window=synth.hann(N), nthreads=8)
+    db = engine.spectra(iq, N, k_avg=8, window="hann", output="mean_db", f64=True, rows_f32=rows_f32)
+    assert np.abs(db - 10 * np.log10(ref / 8)).max() <= (1e-5 if rows_f32 else 1e-9)
+
+
+def test_y4096_payload_bytes(engine, oracle):
+    from rtlws import synth
+    iq = synth.tone_noise_iq(6 * 300, N, seed=78)
+    for window in ("rect", "hann"):
+        ref = oracle.batch_spectra_u8(iq, N, K=6, window=_window(synth, window), nthreads=8)
+        for gain in (0, 15, -25):
+            got = engine.spectra(iq, N, k_avg=6, window=window, output="payload_u8", gain_db=gain, f64=True)
+            want = np.stack([oracle.spectrum_payload(r, 6, gain) for r in ref])
+            assert got.dtype == np.uint8 and np.array_equal(got, want)      # identical bytes, no +-1 allowance
+
+
+def test_y4096_few_rows(engine, oracle):
+    from rtlws import synth
+    for rows, k in ((1, 2), (2, 8), (5, 3), (1, 1)):
+        iq = synth.uniform_iq(rows * k, N, seed=rows + k)
+        got = engine.spectra(iq, N, k_avg=k, window="hann", f64=True)
+        ref = oracle.batch_spectra_u8(iq, N, K=k, window=synth.hann(N))
+        assert rel_err(got, ref, EPS_STRICT).max() <= STRICT_F64
+
+
+def test_all_128_is_all_zero_y4096(engine):
+    """A constant frame excites bin 0 only, and bin 0 is never output (src/spectrum.c:31): with the window the
+    samples are (x - 128) w = 0 exactly; without it the offset meets w = 1 butterflies only."""
+    iq = np.full((16, N, 2), 128, dtype=np.uint8)
+    for window in ("hann", "rect"):
+        got = engine.spectra(iq, N, k_avg=2, window=window, f64=True)
+        assert not got.any()

@@ -28,9 +28,15 @@
 //   rows    lane (q2, q1) of wavefront w ends with bins k = q1 + 16 q2 + 256 q3, q3 over its sixteen registers
 //           -- runs of 4 bins, 16 apart: once per ROW (K frames) the values go through the (then idle) buffer so
 //           that every store instruction writes consecutive bytes.  Cheap for K >= 2, the rows this kernel is for.
+//   samples  sixteen 2-byte loads per lane and frame cost this kernel a quarter of its time (the vector-memory
+//           issue of 64 such instructions per frame, profiles/r06_f64_4096_diag.txt "noload"): every wavefront
+//           instead copies ITS sixteen 128-byte pieces of the next frame into a 2 KiB LDS buffer of its own with
+//           two global_load_lds_dwordx4 (LDS-DMA: no registers, two vector-memory instructions per wavefront
+//           and frame) while the current frame is transformed, and reads them back with sixteen ds_read_u16.
+//           Wavefront-private: no barrier; the copies are retired (vmcnt) at the top of the next frame.
 // The 1/128 input scale rides on nothing: samples enter as (x - 128) w, the power sums are scaled by 2^-14 (exact)
-// once per row.  Per frame: 2 barriers (around exchange 1), 64 LDS instructions per lane (72 before), 636 f64
-// operations per lane with eight of the 16 Hann weights in registers and w_(r+8) = 1 - w_r (678 before).  Results equal spectrum_f64_fused.hip's
+// once per row.  Per frame: 2 barriers (around exchange 1), 64 LDS instructions per lane (72 before) + 16 two-byte reads, 632 f64
+// operations per lane with twelve of the 16 Hann weights in registers and w_(r+8) = 1 - w_r for the rest (678 before).  Results equal spectrum_f64_fused.hip's
 // to rounding; tests/test_f64_4096y_gpu.py holds both against the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,7 +52,33 @@ using namespace f64;
 
 constexpr int Y_ROW = 272;                       // exchange-1 row: 256 elements padded to 17 x 16 (double2 units)
 constexpr int Y_ELEMS = 16 * Y_ROW;              // 4 352 double2 = 69 632 B; wavefront w's quarter: [w * 1088, (w + 1) * 1088)
-constexpr size_t Y_LDS_BYTES = (size_t)(Y_ELEMS + 1) * 16;     // + the DC hand-over slot
+constexpr int Y_RAW_BYTES = 4 * 2048;            // the wavefronts' raw-sample buffers, FIRST in the workgroup's LDS (M0 carries a 16-bit address)
+constexpr size_t Y_LDS_BYTES = (size_t)Y_RAW_BYTES + (size_t)(Y_ELEMS + 1) * 16;     // + the DC hand-over slot: 77 840 B, two workgroups per CU
+
+// This wavefront's sixteen 128-byte pieces of `frame` -- samples 256 r + 64 w .. + 63, r < 16 -- into its raw buffer as
+// [r][64 samples]: lane L of copy j moves 16 bytes of piece r = 8 j + L / 8.  Inline asm on purpose (as in
+// spectrum_fused.hip): hipcc would order every later LDS access of the workgroup's one shared array behind a
+// __builtin_amdgcn_global_load_lds with vmcnt(0).  The ds_read_u16 of the CURRENT frame are waited for first
+// (lgkmcnt(0)): the copies overwrite what they read.  M0 is saved and restored in the same statement.
+// lane index rebuilt where it is needed (two instructions) instead of held in a register through the frame loop,
+// where every register is taken: the allocator spilt such values
+__device__ __forceinline__ int y_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ void y_dma_raw(const SpectraParamsF64& p, long frame, int w, unsigned lds_byte_addr)
+{
+    const int l = y_lane();
+    const uint8_t* g0 = reinterpret_cast<const uint8_t*>(p.in) + frame * 8192 + (l >> 3) * 512 + w * 128 + (l & 7) * 16;
+    const uint8_t* g1 = g0 + 4096;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(lds_byte_addr), d1 = d0 + 1024;
+    unsigned keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, off nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "s"(d0), "s"(d1) : "memory");
+}
 
 size_t spectra_f64_4096y_lds_bytes() { return Y_LDS_BYTES; }
 
@@ -55,22 +87,21 @@ __global__ __launch_bounds__(256, 2) void spectra_f64_4096y(const SpectraParamsF
 {
     constexpr int N = 4096;
     static_assert(!(ROWF32 && OUT == OUT_PAYLOAD), "payload rows are bytes in either form");
-    extern __shared__ __attribute__((aligned(16))) double2 ldsd[];
+    extern __shared__ __attribute__((aligned(16))) double2 lds_all[];
+    double2* const ldsd = lds_all + Y_RAW_BYTES / 16;             // the exchange buffer, behind the raw-sample buffers
 
     const int tid = threadIdx.x;                  // t = 16 r2 + m2 in pass 1
-    const int w = tid >> 6, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;      // (w: wave-uniform, a scalar register)
     const int K = p.k_avg;
     const long ngroups = p.ngroups;
     double2* const slice = ldsd + w * (4 * Y_ROW);               // this wavefront's quarter
     double* const dc_slot = reinterpret_cast<double*>(ldsd + Y_ELEMS);
 
-    unsigned raw[16];
-    auto load_raw = [&](long frame) {
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(p.in) + frame * N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + 256 * r + tid);
-    };
-    if ((long)blockIdx.x < ngroups) load_raw((long)blockIdx.x * K);
+    // this wavefront's raw-sample buffer (2 KiB) and its LDS byte address (for M0); the first frame's copy goes out
+    // before anything else
+    const uint16_t* const rawl = reinterpret_cast<const uint16_t*>(lds_all) + w * 1024 + l;
+    const unsigned raw_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(reinterpret_cast<uint8_t*>(lds_all) + w * 2048);
+    if ((long)blockIdx.x < ngroups) y_dma_raw(p, (long)blockIdx.x * K, w, raw_addr);
 
     // lane constants, resident for the life of the (persistent) workgroup: pass 2's pairs of alpha = W_256^q1
     // (lane (q1, m2) = (tid >> 4, tid & 15)), pass 3's of beta = W_4096^(q1 + 16 q2) (lane (q2, q1): the host
@@ -81,16 +112,17 @@ __global__ __launch_bounds__(256, 2) void spectra_f64_4096y(const SpectraParamsF
 #pragma unroll
     for (int m = 0; m < 8; ++m) twB[m] = p.twyb[tid * 8 + m];
     const f2 wcs = WIN ? p.hann_csf[tid] : mk(0.0, 0.0);
-    // (w_(r+8) = 1 - w_r: the second eight are one subtraction per frame each instead of sixteen more registers,
-    // which this kernel does not have -- 250 VGPRs with the eight)
-    double win[8];
+    // (w_(r+8) = 1 - w_r: the last four weights are one subtraction per frame each instead of four register
+    // pairs this kernel does not have -- with all sixteen resident the allocator spills)
+    constexpr int WREG = 12;
+    double win[WREG];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) win[r] = WIN ? hann_w(r, wcs) : 1.0;
+    for (int r = 0; r < WREG; ++r) win[r] = WIN ? hann_w(r, wcs) : 1.0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(twA[m].x), "v"(twA[m].y), "v"(twB[m].x), "v"(twB[m].y));
     if constexpr (WIN) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(win[r]));
+        for (int r = 0; r < WREG; ++r) asm volatile("" ::"v"(win[r]));
     }
 
     const int wp = l >> 4, wc = l & 15;           // exchange 2, writer side: lane (p, c) = (q1 & 3, m2)
@@ -104,6 +136,17 @@ __global__ __launch_bounds__(256, 2) void spectra_f64_4096y(const SpectraParamsF
         for (int kf = 0; kf < K; ++kf) {
             const long frame = g * K + kf;
             f2 v[16];
+            // this frame's samples have landed in the wavefront's buffer (its copies are the only vector-memory
+            // loads in flight; the previous row's stores are retired with them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned raw[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) raw[r] = rawl[64 * r];
+            {
+                long nf = frame + 1;
+                if (kf + 1 == K) nf = (g + gridDim.x) * K;
+                if (nf < ngroups * K) y_dma_raw(p, nf, w, raw_addr);       // (wave-uniform; waits for the reads above)
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // rectangular: (double)u8, the 128 offset kept (it only reaches bin 0, which is never output:
@@ -111,17 +154,11 @@ __global__ __launch_bounds__(256, 2) void spectra_f64_4096y(const SpectraParamsF
                 // rounding, the same value as fma(x, w, -128 w), without sixteen more lane constants
                 if constexpr (WIN) {
                     const int re = (int)(raw[r] & 0xffu) - 128, im = (int)((raw[r] >> 8) & 0xffu) - 128;
-                    const double wr = r < 8 ? win[r] : 1.0 - win[r - 8];
+                    const double wr = r < WREG ? win[r] : 1.0 - win[r - 8];
                     v[r] = mk((double)re * wr, (double)im * wr);
                 } else {
                     v[r] = mk((double)(raw[r] & 0xffu), (double)((raw[r] >> 8) & 0xffu));
                 }
-            }
-            {
-                long nf = frame + 1;
-                if (kf + 1 == K) nf = (g + gridDim.x) * K;
-                if (nf >= ngroups * K) nf = frame;        // in bounds, result unused
-                load_raw(nf);
             }
 
             // ---- pass 1: radix-16 over r; slot s holds q1 = rev16(s)
@@ -171,10 +208,9 @@ __global__ __launch_bounds__(256, 2) void spectra_f64_4096y(const SpectraParamsF
 
         // ---- row: DC-slot rule (src/spectrum.c:25-33: slot N/2 -- bin 0: wavefront 0, lane 0, slot 0 -- takes
         // sum_k (K-k) P_k[N-1]), epilogue, and the trip through the buffer that makes the stores consecutive
-        // (the row's addresses are rebuilt from an opaque copy of the thread index: hoisted out of the row loop
-        // they would be live through the frame loop, where every register is taken -- the allocator spilt them)
-        int tr = tid;
-        asm volatile("" : "+v"(tr));
+        // (the row's addresses are rebuilt from the lane index: hoisted out of the row loop they would be live
+        // through the frame loop)
+        const int tr = 64 * w + y_lane();
         if (tr == 255) *dc_slot = wdc;
         __syncthreads();                // every wavefront is through its last pass-3 reads; the DC value is there
         if (tr == 0) acc[0] = *dc_slot;

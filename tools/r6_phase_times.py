@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Where a frame of spectrum_f64_4096y.hip spends its shader clocks (diagnostic; needs the -DRTLWS_Y_STAMP build:
+make -C rtl-ws_amd yvariant NAME=y_stamp EXTRA=-DRTLWS_Y_STAMP, RTLWS_HIP_LIB=rtl-ws_amd/lib/variants/y_stamp/librtlws_hip.so).
+Every wavefront sums, over its frames, the clocks between phase boundaries and leaves the sums in the head of an
+output row; this prints the mean per frame and phase over all wavefronts, and the spread of the wavefronts' lifetimes.
+
+usage (GPU box): python3 tools/r6_phase_times.py [workload]        (RTLWS_F64_BLOCKS_PER_CU=1: one workgroup per CU)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "rtl-ws_amd"))
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+import rtlws            # noqa: E402
+import bench            # noqa: E402
+
+PHASES = ["read samples, next copy, convert, window, pass 1", "barrier 1", "exchange-1 writes + barrier 2", "exchange-1 reads + pass 2",
+          "exchange 2 (writes, reads)", "pass 3 + |X|^2", "row epilogue (per row)", "wait for the samples' copy"]
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "hann_4096pt_k8_db_f64c_f32o"
+    n_fft, k_avg, window, output, cic_r, frames = bench.WORKLOADS[name]
+    prec = bench.precision_of(name)
+    dev = torch.device("cuda", 0)
+    eng = rtlws.Engine(0)
+    stream = rtlws.torch_stream_handle()
+    src = torch.randint(0, 256, (frames, n_fft, 2), dtype=torch.uint8, device=dev)
+    desc = rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0, rtlws.FLAG_ROWS_F32 if prec == "f64c_f32o" else 0)
+    odt = torch.float64 if prec == "f64" else torch.float32
+    dst = torch.empty((frames // k_avg, n_fft), dtype=odt, device=dev)
+    for _ in range(300):
+        eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    rows = dst.cpu().numpy()
+    cus = eng.get_option("cu_count")
+    per_cu = int(os.environ.get("RTLWS_F64_BLOCKS_PER_CU", "2") or 2)
+    nwaves = min(cus * per_cu * 4, rows.shape[0])
+    raw = np.stack([rows[i].view(np.uint64)[:12] for i in range(nwaves)])
+    ok = raw[:, 11] == 0x5354414d50          # records a later row store did not overwrite
+    st = raw[ok].astype(np.float64)
+    nfr = st[:, 8]
+    print("%s, %d workgroup(s) per CU: %d of %d wavefront records intact, %.1f frames each" % (name, per_cu, st.shape[0], nwaves, nfr.mean()))
+    tot = 0.0
+    for i, ph in enumerate(PHASES):
+        per = st[:, i] / nfr
+        tot += per.mean()
+        print("  %-40s %8.0f shader clocks per frame (min %6.0f, max %6.0f over the wavefronts)" % (ph, per.mean(), per.min(), per.max()))
+    life = (st[:, 10] - st[:, 9]) / 100.0
+    print("  %-40s %8.0f; wavefront lifetime %.1f us mean, %.1f min, %.1f max; first start to last end %.1f us" % (
+        "sum", tot, life.mean(), life.min(), life.max(), (st[:, 10].max() - st[:, 9].min()) / 100.0))
+
+
+main()

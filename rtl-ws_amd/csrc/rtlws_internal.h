@@ -129,6 +129,10 @@ size_t spectra_f64_1024x_lds_bytes(int waves);      // dynamic LDS per workgroup
 // windowed / K-frame 4096-point cmplx_u8 frames: one cross-wavefront exchange per frame (engine option f64_y4096)
 hipError_t launch_spectra_f64_4096y(const SpectraParamsF64&, int blocks, hipStream_t, int device);
 size_t spectra_f64_4096y_lds_bytes();
+// ... two rows in flight per workgroup, their phases one barrier apart (engine option f64_y4096 = 2): one workgroup of
+// eight wavefronts per CU
+hipError_t launch_spectra_f64_4096z(const SpectraParamsF64&, int blocks, hipStream_t, int device);
+size_t spectra_f64_4096z_lds_bytes();
 constexpr bool f64_y4096_kind(int n_fft, int in_kind, bool win, int k_avg)
 {
     return n_fft == 4096 && in_kind == IN_CU8 && (win || k_avg > 1);

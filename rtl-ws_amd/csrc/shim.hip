@@ -77,7 +77,9 @@ struct EngineOpts {
     int f64_fused = 1;           // RTLWS_F64_FUSED=0: f64 batches stay on the row-per-workgroup kernel
     int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
     int f64_x1024 = 1;           // RTLWS_F64_X1024=0: rectangular 1024-point u8 frames stay on the two-transposition kernel
-    int f64_y4096 = 1;           // RTLWS_F64_Y4096=0: windowed / K-frame 4096-point u8 frames stay on the two-cross-exchange kernel
+    int f64_y4096 = 2;           // RTLWS_F64_Y4096: windowed / K-frame 4096-point u8 frames: 0 = the two-cross-exchange kernel,
+                                 // 1 = one cross exchange (spectrum_f64_4096y.hip), 2 = ... and two anti-phase teams per CU (4096z)
+    bool f64_z_ok = true;        // the device's LDS limit per workgroup holds the two-team form (152 KiB)
     int f64_x_waves = 0;         // RTLWS_F64_X_WAVES: wavefronts per workgroup of that kernel: 0 = by batch size, 1, 8
     bool f64_x_waves8_ok = true; // the device's LDS limit per workgroup holds the eight-wavefront form (136 KiB)
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
@@ -437,7 +439,8 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.f64_blocks_per_cu = env_int("RTLWS_F64_BLOCKS_PER_CU", 0);
     e->opt.f64_x1024 = env_int("RTLWS_F64_X1024", 1);
     e->opt.f64_x_waves = env_int("RTLWS_F64_X_WAVES", 0);
-    e->opt.f64_y4096 = env_int("RTLWS_F64_Y4096", 1);
+    e->opt.f64_y4096 = env_int("RTLWS_F64_Y4096", 2);
+    if (e->opt.f64_y4096 < 0 || e->opt.f64_y4096 > 2) e->opt.f64_y4096 = 2;
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
     // the eight-wavefront workgroups of spectrum_f64_1024x.hip need 136 KiB of LDS: where the device cannot give
@@ -446,6 +449,7 @@ rtlws_engine* rtlws_engine_create(int device)
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess ||
         (size_t)lds_max < rtlws::spectra_f64_1024x_lds_bytes(8))
         e->opt.f64_x_waves8_ok = false;
+    if ((size_t)lds_max < rtlws::spectra_f64_4096z_lds_bytes()) e->opt.f64_z_ok = false;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_err("hipStreamCreate", err);
@@ -478,7 +482,7 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
-    else if (k == "f64_y4096") e->opt.f64_y4096 = value != 0;
+    else if (k == "f64_y4096") e->opt.f64_y4096 = (value >= 0 && value <= 2) ? value : 2;
     else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
@@ -558,6 +562,7 @@ int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft)
                     for (int w = 0; w <= 1 && err == hipSuccess; ++w) {
                         p.window = w ? &dummy_window : nullptr;
                         if (err == hipSuccess) err = rtlws::launch_spectra_f64_4096y(p, 0, e->stream, e->device);
+                        if (err == hipSuccess && e->opt.f64_z_ok) err = rtlws::launch_spectra_f64_4096z(p, 0, e->stream, e->device);
                         for (int in_kind : {(int)rtlws::IN_CU8, (int)rtlws::IN_CS32, (int)rtlws::IN_RF32, (int)rtlws::IN_CU8_CIC8,
                                             (int)rtlws::IN_CU8_CIC10, (int)rtlws::IN_CU8_CIC12})
                             if (err == hipSuccess) err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, 0, e->stream, e->device);
@@ -945,8 +950,15 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
             return rtlws::launch_spectra_f64_1024x(pp, (int)blocks, waves, s);
         }
         // windowed / K-frame 4096-point cmplx_u8 frames: one cross-wavefront exchange per frame instead of two
-        if (rtlws::f64_y4096_kind(d->n_fft, in_kind, pp.window != nullptr, d->k_avg) && e->opt.f64_y4096 && pp.twyb)
+        if (rtlws::f64_y4096_kind(d->n_fft, in_kind, pp.window != nullptr, d->k_avg) && e->opt.f64_y4096 && pp.twyb) {
+            if (e->opt.f64_y4096 == 2 && e->opt.f64_z_ok) {
+                // one workgroup of two teams per CU, a row per team: never more workgroups than pairs of rows
+                long zb = (pp.ngroups + 1) / 2;
+                if (zb > e->cu_count) zb = e->cu_count;
+                return rtlws::launch_spectra_f64_4096z(pp, (int)zb, s, e->device);
+            }
             return rtlws::launch_spectra_f64_4096y(pp, (int)blocks, s, e->device);
+        }
         switch (d->n_fft) {
         case 1024: return rtlws::launch_spectra_f64_fused_1024(pp, in_kind, (int)blocks, s, e->device);
         case 2048: return rtlws::launch_spectra_f64_fused_2048(pp, in_kind, (int)blocks, s, e->device);

@@ -27,8 +27,11 @@ def test_y4096_vs_oracle_and_the_two_exchange_kernel(engine, oracle, window, k_a
     iq[3] = 128                       # a constant frame
     iq[4] = synth.pure_tone_iq(1, N, seed=2)[0]
     iq[5] = synth.uniform_iq(1, N, seed=2)[0]
-    assert engine.get_option("f64_y4096") == 1
+    assert engine.get_option("f64_y4096") == 2          # the default: two anti-phase teams per CU (spectrum_f64_4096z.hip)
     got = engine.spectra(iq, N, k_avg=k_avg, window=window, f64=True, rows_f32=rows_f32)
+    with engine.option("f64_y4096", 1):                 # one team per workgroup (spectrum_f64_4096y.hip): the same transform
+        one = engine.spectra(iq, N, k_avg=k_avg, window=window, f64=True, rows_f32=rows_f32)
+    assert rel_err(got, one, EPS_STRICT).max() <= (2.0 ** -23 if rows_f32 else 1e-13)
     assert got.shape == (rows, N) and got.dtype == (np.float32 if rows_f32 else np.float64)
     ref = oracle.batch_spectra_u8(iq, N, K=k_avg, window=_window(synth, window), nthreads=8)
     bound = 2.0 ** -24 * 1.001 if rows_f32 else STRICT_F64
@@ -36,7 +39,7 @@ def test_y4096_vs_oracle_and_the_two_exchange_kernel(engine, oracle, window, k_a
     with engine.option("f64_y4096", 0):
         old = engine.spectra(iq[:40 * k_avg], N, k_avg=k_avg, window=window, f64=True, rows_f32=rows_f32)
     assert rel_err(got[:40], old, EPS_STRICT).max() <= bound
-    assert engine.get_option("f64_y4096") == 1
+    assert engine.get_option("f64_y4096") == 2
 
 
 def test_y4096_dc_slot_weights(engine, oracle):
@@ -75,13 +78,17 @@ def test_y4096_payload_bytes(engine, oracle):
             assert got.dtype == np.uint8 and np.array_equal(got, want)      # identical bytes, no +-1 allowance
 
 
-def test_y4096_few_rows(engine, oracle):
+@pytest.mark.parametrize("form", [1, 2])
+def test_y4096_few_rows(engine, oracle, form):
+    """Fewer rows than teams, odd row counts (team 1 short of one row), one row: every barrier still met."""
     from rtlws import synth
-    for rows, k in ((1, 2), (2, 8), (5, 3), (1, 1)):
+    engine.set_option("f64_y4096", form)
+    for rows, k in ((1, 2), (2, 8), (5, 3), (1, 1), (3, 1), (513, 2), (1023, 1)):
         iq = synth.uniform_iq(rows * k, N, seed=rows + k)
         got = engine.spectra(iq, N, k_avg=k, window="hann", f64=True)
-        ref = oracle.batch_spectra_u8(iq, N, K=k, window=synth.hann(N))
+        ref = oracle.batch_spectra_u8(iq, N, K=k, window=synth.hann(N), nthreads=8)
         assert rel_err(got, ref, EPS_STRICT).max() <= STRICT_F64
+    engine.set_option("f64_y4096", 2)
 
 
 def test_all_128_is_all_zero_y4096(engine):

@@ -173,9 +173,12 @@ __global__ __launch_bounds__(512, 2) void spectra_f64_4096z(const SpectraParamsF
         wdc = 0.0;
     };
 
+    // the team's position: frame kf of row `row` (no division in the loop: the counters step)
+    long row = 0;
+    int kf = 0;
     for (long slot = 0; slot <= last_slot; ++slot) {
         const long mine = slot - team;            // this team's own slot count: even = A B of frame mine / 2, odd = C of it
-        const long f = mine >> 1;                 // the team's frame index
+        const long f = mine >> 1;                 // the team's frame index = row * K + kf
         if (mine >= 0 && mine < 2 * my_frames && !(mine & 1)) {
             // ---- A: this frame's samples have landed in the wavefront's buffer (its copies are the only vector-memory
             // loads in flight; the stores of the row before last are long retired)
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(512, 2) void spectra_f64_4096z(const SpectraParamsF
 #pragma unroll
             for (int r = 0; r < 16; ++r) raw[r] = rawl[64 * r];
             if (f + 1 < my_frames) {                                 // (wave-uniform; waits for the reads above)
-                const long nrow = (f + 1) / K;
-                z_dma_raw(p, (g0 + nrow * stride) * K + (f + 1 - nrow * K), w, raw_addr);
+                const long nframe = kf + 1 < K ? (g0 + row * stride) * K + kf + 1 : (g0 + (row + 1) * stride) * K;
+                z_dma_raw(p, nframe, w, raw_addr);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -208,7 +211,6 @@ __global__ __launch_bounds__(512, 2) void spectra_f64_4096z(const SpectraParamsF
             for (int s = 0; s < 16; ++s) ldsd[rev16(s) * Z_ROW + tid] = v[s];
             // a row ended in the team's previous slot: its epilogue and stores go here -- the samples and the
             // transform's registers are dead, and the next wait for vector memory is two slots away
-            const long row = f / K, kf = f - row * K;
             if (kf == 0 && f > 0) finish_row(g0 + (row - 1) * stride);
         } else if (mine >= 0 && mine < 2 * my_frames) {
             // ---- C: lane (q1, m2) = (tid >> 4, tid & 15) reads r2 = 0 .. 15: rows 4w .. 4w+3 only
@@ -233,8 +235,6 @@ __global__ __launch_bounds__(512, 2) void spectra_f64_4096z(const SpectraParamsF
             fft_last<16>(v, 0, twB);
             // |X|^2, accumulate; bin N-1 (q1 = q2 = q3 = 15: wavefront 3, lane 63, slot 15) also feeds the DC slot
             // with weight K - kf
-            const long row = f / K;
-            const int kf = (int)(f - row * K);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 if (u == 15) {
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void spectra_f64_4096z(const SpectraParamsF
                 }
             }
             if (kf == K - 1 && tid == 255) *dc_slot = wdc;      // read by the team's first thread after the next barrier
+            if (++kf == K) { kf = 0; ++row; }
         } else if (mine == 2 * my_frames && my_frames > 0) {
             finish_row(g0 + (my_rows - 1) * stride);            // the team's last row
         }

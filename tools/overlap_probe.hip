@@ -107,8 +107,10 @@ int main()
         CHECK(hipMemcpy(h.data(), d, blocks * sizeof(Rec), hipMemcpyDeviceToHost));
         // per SIMD: sum the instructions of its wavefronts, divide by the longest wavefront's clocks
         double fma = 0, ldsn = 0, clk = 0; int roles[4] = {0, 0, 0, 0};
-        for (const Rec& r : h) { fma += (double)r.fma; ldsn += (double)r.lds; if ((double)r.clk > clk) clk = (double)r.clk; roles[r.role & 3]++; }
+        double rclk[4] = {0, 0, 0, 0};
+        for (const Rec& r : h) { fma += (double)r.fma; ldsn += (double)r.lds; if ((double)r.clk > clk) clk = (double)r.clk; roles[r.role & 3]++; rclk[r.role & 3] += (double)r.clk; }
         const double simds = 4.0 * p.multiProcessorCount;
+        printf("    mean wavefront clocks by role: F %.0f  L %.0f  M %.0f\n", roles[0] ? rclk[0] / roles[0] : 0.0, roles[1] ? rclk[1] / roles[1] : 0.0, roles[2] ? rclk[2] / roles[2] : 0.0);
         printf("%-16s %12.4f %12.4f %10.2f %10.2f   roles F/L/M/idle %d/%d/%d/%d, longest wavefront %.0f clocks\n", m.name, fma / simds / clk, ldsn / simds / clk,
                fma > 0 ? simds * clk / fma : 0.0, ldsn > 0 ? simds * clk / ldsn : 0.0, roles[0], roles[1], roles[2], roles[3], clk);
     }

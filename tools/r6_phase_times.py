@@ -33,9 +33,20 @@ def main():
     odt = torch.float64 if prec == "f64" else torch.float32
     nrows = frames // k_avg
     dst = torch.zeros((nrows + 64, n_fft), dtype=odt, device=dev)        # the stamp records go behind the last row
+    dst2 = torch.zeros_like(dst)
     for _ in range(300):
         eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
+    e1.record()
+    # two consecutive launches into two buffers: the gap between the first one's last wavefront and the second one's first
+    eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
+    eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst2.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    print("HIP events: %.2f us per launch over 200 back-to-back launches" % (e0.elapsed_time(e1) * 1e3 / 200))
     cus = eng.get_option("cu_count")
     per_cu = int(os.environ.get("RTLWS_F64_BLOCKS_PER_CU", "2") or 2)
     nwaves = cus * per_cu * 4
@@ -52,6 +63,14 @@ def main():
     life = (st[:, 10] - st[:, 9]) / 100.0
     print("  %-40s %8.0f; wavefront lifetime %.1f us mean, %.1f min, %.1f max; first start to last end %.1f us" % (
         "sum", tot, life.mean(), life.min(), life.max(), (st[:, 10].max() - st[:, 9].min()) / 100.0))
+    raw2 = dst2[nrows:].cpu().numpy().reshape(-1).view(np.uint64)[:12 * nwaves].reshape(nwaves, 12)
+    st2 = raw2[raw2[:, 11] == 0x5354414d50].astype(np.float64)
+    if st2.shape[0]:
+        print("  next launch: its first wavefront's stamp comes %.1f us after this launch's last wavefront ended, %.1f us after its first started" % (
+            (st2[:, 9].min() - st[:, 10].max()) / 100.0, (st2[:, 9].min() - st[:, 9].min()) / 100.0))
+        starts = np.sort(st2[:, 9]) - st2[:, 9].min()
+        print("  start stamps of the next launch's wavefronts, us after the first: median %.1f, 90 %% %.1f, last %.1f" % (
+            np.median(starts) / 100.0, np.percentile(starts, 90) / 100.0, starts[-1] / 100.0))
 
 
 main()

@@ -28,25 +28,28 @@ def main():
     dev = torch.device("cuda", 0)
     eng = rtlws.Engine(0)
     stream = rtlws.torch_stream_handle()
-    src = torch.randint(0, 256, (frames, n_fft, 2), dtype=torch.uint8, device=dev)
+    # R6_SETS=4: four rotating input sets (HBM-streamed, as bench.py); default 1 (the 128 MiB stay in the Infinity Cache)
+    sets = int(os.environ.get("R6_SETS", "1"))
+    srcs = [torch.randint(0, 256, (frames, n_fft, 2), dtype=torch.uint8, device=dev) for _ in range(sets)]
+    src = srcs[0]
     desc = rtlws.make_desc(n_fft, k_avg, "cu8", window, output, cic_r, 0, rtlws.FLAG_ROWS_F32 if prec == "f64c_f32o" else 0)
     odt = torch.float64 if prec == "f64" else torch.float32
     nrows = frames // k_avg
     dst = torch.zeros((nrows + 64, n_fft), dtype=odt, device=dev)        # the stamp records go behind the last row
     dst2 = torch.zeros_like(dst)
-    for _ in range(300):
-        eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
+    for i in range(300):
+        eng.spectra_batch_f64(desc, srcs[i % sets].data_ptr(), frames, dst.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(200):
-        eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
+    for i in range(200):
+        eng.spectra_batch_f64(desc, srcs[i % sets].data_ptr(), frames, dst.data_ptr(), stream=stream)
     e1.record()
     # two consecutive launches into two buffers: the gap between the first one's last wavefront and the second one's first
-    eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst.data_ptr(), stream=stream)
-    eng.spectra_batch_f64(desc, src.data_ptr(), frames, dst2.data_ptr(), stream=stream)
+    eng.spectra_batch_f64(desc, srcs[1 % sets].data_ptr(), frames, dst.data_ptr(), stream=stream)
+    eng.spectra_batch_f64(desc, srcs[2 % sets].data_ptr(), frames, dst2.data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    print("HIP events: %.2f us per launch over 200 back-to-back launches" % (e0.elapsed_time(e1) * 1e3 / 200))
+    print("HIP events: %.2f us per launch over 200 back-to-back launches, %d input set(s)" % (e0.elapsed_time(e1) * 1e3 / 200, sets))
     cus = eng.get_option("cu_count")
     per_cu = int(os.environ.get("RTLWS_F64_BLOCKS_PER_CU", "2") or 2)
     nwaves = cus * per_cu * 4

@@ -365,6 +365,7 @@ def energy_counter_for(rtlws, device_index):
 
 
 ENERGY_LAUNCHES = 600          # launches of the energy leg (after the timed region, untimed)
+CLOCK_LAUNCHES = 300           # launches of the clock leg (after the energy leg, beside the probe wavefront)
 
 
 def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0):
@@ -433,16 +434,10 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # one sleeping wavefront on a queue of its own reads the shader-clock and 100 MHz counters when the
-    # timed region starts and when it ends: the clock THESE launches ran at (include/rtlws_hip.h,
-    # rtlws_clock_probe_*).  Started before t0; told to leave by a write-value packet behind the last launch,
-    # which the closing device synchronise then waits for (one poll, ~0.5 us).
-    probe = None
-    if ctx.get("clock_probe", True):
-        try:                                  # an auxiliary measurement: without it the line has no sclk_ghz
-            probe = eng.clock_probe_start()
-        except Exception as ex:
-            print("bench.py: clock probe not started (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
+    # (No probe wavefront beside the timed launches -- rounds 4-5 had one: it takes registers on one SIMD, and a
+    # kernel that fills a SIMD's registers then has a workgroup that cannot be resident and runs after the others:
+    # +1..3 % on most workloads, +38 % on the 4096-point f64 rows, profiles/r06_clock_probe_perturbation.txt.  The
+    # shader clock is measured on a leg of its own, below.)
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
     tA = time.perf_counter()
@@ -451,26 +446,16 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     tB = time.perf_counter()
     L.rtlws_event_record(ev1, eng.h, stream)
     tC = time.perf_counter()
-    if probe is not None:
-        # the device itself tells the probe to leave once the launches above have drained
-        try:
-            eng.clock_probe_signal_on_stream(probe, stream)
-        except Exception as ex:
-            print("bench.py: clock probe signal failed (%s); stopping it from the host" % ex, file=sys.stderr)
-            eng.clock_probe_signal(probe)
     tD = time.perf_counter()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0        # this rank's launches, before waiting for the others
     if os.environ.get("RTLWS_BENCH_DEBUG"):
-        print("DEBUG %s probe=%s: ev0 %.3f ms, enqueue %.3f, ev1 %.3f, stream sync %.3f, device sync %.3f, total %.3f" % (
-            name, probe is not None, 1e3 * (tA - t0), 1e3 * (tB - tA), 1e3 * (tC - tB), 1e3 * (tD - tC),
+        print("DEBUG %s: ev0 %.3f ms, enqueue %.3f, ev1 %.3f, stream sync %.3f, device sync %.3f, total %.3f" % (
+            name, 1e3 * (tA - t0), 1e3 * (tB - tA), 1e3 * (tC - tB), 1e3 * (tD - tC),
             1e3 * (t0 + own_elapsed - tD), 1e3 * own_elapsed), file=sys.stderr)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # (after the clock has stopped: releasing the probe's queue and pinned words takes ~1 ms)
-    sclk_ghz, probe_s = eng.clock_probe_stop(probe) if probe is not None else (None, None)
-    per_rank_sclk = gather_ranks(torch, dist, sclk_ghz or 0.0, ctx.get("reduce_device", device))
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
@@ -493,6 +478,34 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                           "source": "rocm_smi rsmi_dev_energy_count_get of the GPU at this bus id around %d further "
                                     "launches after the timed region (package energy accumulator; not part of "
                                     "`value`)" % ENERGY_LAUNCHES}
+    # clock leg (after the clock has stopped, after the energy leg): CLOCK_LAUNCHES more launches of the same step with
+    # ONE sleeping wavefront on a queue of its own beside them, which reads the shader-clock and 100 MHz counters when
+    # the leg starts and when the device itself tells it to leave (a write-value packet behind the last launch):
+    # the clock the governor gives this step (include/rtlws_hip.h, rtlws_clock_probe_*).  The probe costs the kernel
+    # registers on one SIMD: the leg's own launch time is in the line, and where it is more than 3 % over the timed
+    # launches' the clock is reported as that of a PERTURBED run and nothing is derived from it.
+    sclk_ghz, probe_s, clock_leg_us = None, None, None
+    if ctx.get("clock_probe", True):
+        try:
+            probe = eng.clock_probe_start()
+            evc0, evc1 = L.rtlws_event_create(), L.rtlws_event_create()
+            L.rtlws_event_record(evc0, eng.h, stream)
+            for i in range(CLOCK_LAUNCHES):
+                step(i)
+            L.rtlws_event_record(evc1, eng.h, stream)
+            try:
+                eng.clock_probe_signal_on_stream(probe, stream)
+            except Exception as ex:
+                print("bench.py: clock probe signal failed (%s); stopping it from the host" % ex, file=sys.stderr)
+                eng.clock_probe_signal(probe)
+            torch.cuda.synchronize()
+            sclk_ghz, probe_s = eng.clock_probe_stop(probe)
+            clock_leg_us = 1e3 * L.rtlws_event_elapsed_ms(evc0, evc1) / CLOCK_LAUNCHES
+            L.rtlws_event_destroy(evc0)
+            L.rtlws_event_destroy(evc1)
+        except Exception as ex:                  # an auxiliary measurement: without it the line has no sclk_ghz
+            print("bench.py: clock leg failed (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
+    per_rank_sclk = gather_ranks(torch, dist, sclk_ghz or 0.0, ctx.get("reduce_device", device))
     rdev = ctx.get("reduce_device", device)
     elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], rdev)
     per_rank_own = gather_ranks(torch, dist, 1e3 * own_elapsed / steps, rdev)
@@ -562,10 +575,18 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         if energy is not None:
             result["roofline"]["energy"] = energy
         if sclk_ghz:
+            perturbed = clock_leg_us is not None and clock_leg_us > 1.03 * 1e6 * avg_launch_s
             result["roofline"]["sclk_ghz"] = sclk_ghz
-            result["roofline"]["sclk_source"] = ("d(s_memtime) / d(s_memrealtime) x 100 MHz of a probe wavefront resident "
-                                                 "beside the timed launches (%.1f ms, this run)" % (1e3 * probe_s))
-            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
+            result["roofline"]["sclk_leg_avg_launch_us"] = clock_leg_us
+            result["roofline"]["sclk_perturbed"] = perturbed
+            result["roofline"]["sclk_source"] = (
+                "d(s_memtime) / d(s_memrealtime) x 100 MHz of a probe wavefront resident beside %d further launches of "
+                "the same step after the timed region and the energy leg (%.1f ms, this run); the timed launches run "
+                "WITHOUT it%s" % (CLOCK_LAUNCHES, 1e3 * probe_s,
+                                  ": here the probe's registers cost the kernel a workgroup's residency (the leg's launches "
+                                  "are more than 3 % slower than the timed ones), so this is the clock of a PERTURBED run"
+                                  if perturbed else ""))
+            vf = None if perturbed else valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
             if vf is not None:
                 result["roofline"].update(vf)
         if world > 1:
@@ -1027,8 +1048,7 @@ def main(argv=None):
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration (roofline.box)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy leg after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
-                    help="no probe wavefront beside the timed launches (rocprofv3 --pmc serialises kernels: the "
-                         "launches would wait for the probe)")
+                    help="no clock leg (rocprofv3 --pmc serialises kernels: its launches would wait for the probe)")
     ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 

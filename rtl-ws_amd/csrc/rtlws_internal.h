@@ -93,9 +93,6 @@ struct SpectraParamsF64 {
     // spectrum_f64_1024x.hip (1024 = 4 x 16 x 16, one LDS transposition)
     const double2* twxa;     // [4][8] (cos, tan) pairs of pass A's geometric pre-twiddle alpha = W_64^p
     const double2* twxb;     // [64][16] W_1024^(c (4 q + p)) / 128, lane 16 p + c, slot s: q = rev16(s)
-    // spectrum_f64_4096y.hip (4096 = 16 x 16 x 16, one cross-wavefront exchange, no twiddle multiplies)
-    const double2* twyb;     // [256][8] (cos, tan) pairs of pass 3's beta = W_4096^(q1 + 16 q2), by thread:
-                             // thread 64 w + l is lane (q2, q1) = (l >> 2, 4 w + (l & 3))
 };
 
 // which f64 descriptors take the fused throughput kernel (the rest: spectrum_f64.hip): the three
@@ -126,17 +123,6 @@ constexpr int f64_fused_blocks_per_cu(int n_fft) { return 8 / (n_fft / 1024); }
 // rectangular 1024-point cmplx_u8 frames: the one-transposition kernel (engine option f64_x1024)
 hipError_t launch_spectra_f64_1024x(const SpectraParamsF64&, int blocks, int waves, hipStream_t);
 size_t spectra_f64_1024x_lds_bytes(int waves);      // dynamic LDS per workgroup of that form (waves = 1 | 8)
-// windowed / K-frame 4096-point cmplx_u8 frames: one cross-wavefront exchange per frame (engine option f64_y4096)
-hipError_t launch_spectra_f64_4096y(const SpectraParamsF64&, int blocks, hipStream_t, int device);
-size_t spectra_f64_4096y_lds_bytes();
-// ... two rows in flight per workgroup, their phases one barrier apart (engine option f64_y4096 = 2): one workgroup of
-// eight wavefronts per CU
-hipError_t launch_spectra_f64_4096z(const SpectraParamsF64&, int blocks, hipStream_t, int device);
-size_t spectra_f64_4096z_lds_bytes();
-constexpr bool f64_y4096_kind(int n_fft, int in_kind, bool win, int k_avg)
-{
-    return n_fft == 4096 && in_kind == IN_CU8 && (win || k_avg > 1);
-}
 hipError_t launch_spectra_f64_fused_1024(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_2048(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);
 hipError_t launch_spectra_f64_fused_4096(const SpectraParamsF64&, int in_kind, int blocks, hipStream_t, int device);

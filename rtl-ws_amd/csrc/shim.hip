@@ -61,7 +61,6 @@ struct Tables {
     double2* hann_cs64 = nullptr;   //   [T] (0.5 cos, 0.5 sin)(2 pi t / N)
     double2* twxa_64 = nullptr;     // spectrum_f64_1024x.hip (N = 1024): [4][8] pass-A (cos, tan) pairs
     double2* twxb_64 = nullptr;     //   [64][16] inner twiddles x lane constant / 128
-    double2* twyb_64 = nullptr;     // spectrum_f64_4096y.hip (N = 4096): [256][8] pass-3 (cos, tan) pairs, by thread
 };
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;
@@ -77,9 +76,6 @@ struct EngineOpts {
     int f64_fused = 1;           // RTLWS_F64_FUSED=0: f64 batches stay on the row-per-workgroup kernel
     int f64_blocks_per_cu = 0;   // RTLWS_F64_BLOCKS_PER_CU
     int f64_x1024 = 1;           // RTLWS_F64_X1024=0: rectangular 1024-point u8 frames stay on the two-transposition kernel
-    int f64_y4096 = 2;           // RTLWS_F64_Y4096: windowed / K-frame 4096-point u8 frames: 0 = the two-cross-exchange kernel,
-                                 // 1 = one cross exchange (spectrum_f64_4096y.hip), 2 = ... and two anti-phase teams per CU (4096z)
-    bool f64_z_ok = true;        // the device's LDS limit per workgroup holds the two-team form (152 KiB)
     int f64_x_waves = 0;         // RTLWS_F64_X_WAVES: wavefronts per workgroup of that kernel: 0 = by batch size, 1, 8
     bool f64_x_waves8_ok = true; // the device's LDS limit per workgroup holds the eight-wavefront form (136 KiB)
     int cic_direct = 0;          // RTLWS_CIC_DIRECT=1: every R != 8 on per-lane direct loads
@@ -144,7 +140,6 @@ void free_tables(Tables& tb)
     (void)hipFree(tb.hann_cs64);
     (void)hipFree(tb.twxa_64);
     (void)hipFree(tb.twxb_64);
-    (void)hipFree(tb.twyb_64);
     tb = Tables();
 }
 
@@ -314,28 +309,6 @@ int get_tables_f64(rtlws_engine* e, int n_fft, Tables* out)
                 return -3;
             }
         }
-        if (n_fft == 4096) {
-            // spectrum_f64_4096y.hip: pass 3 (radix-16 over m2 on lane (q2, q1)) absorbs what passes 1 and 2 owe,
-            // (W_4096^(q1 + 16 q2))^m2: the pairs of beta^(16/L) W_L^p', beta = W_4096^kk, = W_(4096 L)^(16 kk + 4096 p'),
-            // in fft_last<16>'s order; thread 64 w + l is lane (q2, q1) = (l >> 2, 4 w + (l & 3)): kk = q1 + 16 q2
-            std::vector<double2> hy((size_t)256 * 8);
-            for (int tid = 0; tid < 256; ++tid) {
-                const int wv = tid >> 6, ln = tid & 63;
-                const long kk = 4 * wv + (ln & 3) + 16 * (ln >> 2);
-                int k = 0;
-                for (int L = 2; L <= 16; L *= 2)
-                    for (int pp = 0; pp < (L >= 4 ? L / 4 : 1); ++pp) {
-                        long double c, sn;
-                        wn(16 * kk + 4096L * pp, 4096L * L, &c, &sn);
-                        if (c == 0.0L) c = 1e-20L;
-                        hy[(size_t)tid * 8 + k++] = make_double2((double)c, (double)(sn / c));
-                    }
-            }
-            if (!upload_table(hy, &tb.twyb_64)) {
-                free_tables(tb);
-                return -3;
-            }
-        }
     }
     e->tables[kF64Key + n_fft] = tb;
     *out = tb;
@@ -439,8 +412,6 @@ rtlws_engine* rtlws_engine_create(int device)
     e->opt.f64_blocks_per_cu = env_int("RTLWS_F64_BLOCKS_PER_CU", 0);
     e->opt.f64_x1024 = env_int("RTLWS_F64_X1024", 1);
     e->opt.f64_x_waves = env_int("RTLWS_F64_X_WAVES", 0);
-    e->opt.f64_y4096 = env_int("RTLWS_F64_Y4096", 2);
-    if (e->opt.f64_y4096 < 0 || e->opt.f64_y4096 > 2) e->opt.f64_y4096 = 2;
     e->opt.cic_direct = env_int("RTLWS_CIC_DIRECT", 0) == 1;
     e->opt.cic_round = env_int("RTLWS_CIC_ROUND", 0);
     // the eight-wavefront workgroups of spectrum_f64_1024x.hip need 136 KiB of LDS: where the device cannot give
@@ -449,7 +420,6 @@ rtlws_engine* rtlws_engine_create(int device)
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess ||
         (size_t)lds_max < rtlws::spectra_f64_1024x_lds_bytes(8))
         e->opt.f64_x_waves8_ok = false;
-    if ((size_t)lds_max < rtlws::spectra_f64_4096z_lds_bytes()) e->opt.f64_z_ok = false;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         set_err("hipStreamCreate", err);
@@ -482,7 +452,6 @@ int rtlws_engine_set_option(rtlws_engine* e, const char* name, int value)
     else if (k == "f64_fused") e->opt.f64_fused = value != 0;
     else if (k == "f64_blocks_per_cu") e->opt.f64_blocks_per_cu = value > 0 ? value : 0;
     else if (k == "f64_x1024") e->opt.f64_x1024 = value != 0;
-    else if (k == "f64_y4096") e->opt.f64_y4096 = (value >= 0 && value <= 2) ? value : 2;
     else if (k == "f64_x_waves") e->opt.f64_x_waves = (value == 1 || value == 8) ? value : 0;
     else if (k == "cic_direct") e->opt.cic_direct = value != 0;
     else if (k == "cic_round") e->opt.cic_round = (value == 1 || value == 2 || value == 4) ? value : 0;
@@ -503,7 +472,6 @@ int rtlws_engine_get_option(const rtlws_engine* e, const char* name)
     if (k == "f64_blocks_per_cu") return e->opt.f64_blocks_per_cu;
     if (k == "f64_x1024") return e->opt.f64_x1024;
     if (k == "f64_x_waves") return e->opt.f64_x_waves;
-    if (k == "f64_y4096") return e->opt.f64_y4096;
     if (k == "cic_direct") return e->opt.cic_direct;
     if (k == "cic_round") return e->opt.cic_round;
     if (k == "cu_count") return e->cu_count;
@@ -561,8 +529,6 @@ int rtlws_engine_prepare_f64(rtlws_engine* e, int n_fft)
                 if (n_fft == 4096)
                     for (int w = 0; w <= 1 && err == hipSuccess; ++w) {
                         p.window = w ? &dummy_window : nullptr;
-                        if (err == hipSuccess) err = rtlws::launch_spectra_f64_4096y(p, 0, e->stream, e->device);
-                        if (err == hipSuccess && e->opt.f64_z_ok) err = rtlws::launch_spectra_f64_4096z(p, 0, e->stream, e->device);
                         for (int in_kind : {(int)rtlws::IN_CU8, (int)rtlws::IN_CS32, (int)rtlws::IN_RF32, (int)rtlws::IN_CU8_CIC8,
                                             (int)rtlws::IN_CU8_CIC10, (int)rtlws::IN_CU8_CIC12})
                             if (err == hipSuccess) err = rtlws::launch_spectra_f64_fused_4096(p, in_kind, 0, e->stream, e->device);
@@ -917,7 +883,6 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
     p.rows_f32 = (d->flags & RTLWS_FLAG_ROWS_F32) && d->output != RTLWS_OUT_PAYLOAD_U8;
     p.twxa = tb.twxa_64;
     p.twxb = tb.twxb_64;
-    p.twyb = tb.twyb_64;
 
     int in_kind = d->input;
     if (d->cic_r > 1) in_kind = cic_in_kind(e, d->cic_r);
@@ -948,16 +913,6 @@ int rtlws_spectra_batch_f64(rtlws_engine* e, const rtlws_spectra_desc* d, const 
             if (!e->opt.f64_x_waves8_ok) waves = 1;
             if (waves >= 8) blocks = e->cu_count;
             return rtlws::launch_spectra_f64_1024x(pp, (int)blocks, waves, s);
-        }
-        // windowed / K-frame 4096-point cmplx_u8 frames: one cross-wavefront exchange per frame instead of two
-        if (rtlws::f64_y4096_kind(d->n_fft, in_kind, pp.window != nullptr, d->k_avg) && e->opt.f64_y4096 && pp.twyb) {
-            if (e->opt.f64_y4096 == 2 && e->opt.f64_z_ok) {
-                // one workgroup of two teams per CU, a row per team: never more workgroups than pairs of rows
-                long zb = (pp.ngroups + 1) / 2;
-                if (zb > e->cu_count) zb = e->cu_count;
-                return rtlws::launch_spectra_f64_4096z(pp, (int)zb, s, e->device);
-            }
-            return rtlws::launch_spectra_f64_4096y(pp, (int)blocks, s, e->device);
         }
         switch (d->n_fft) {
         case 1024: return rtlws::launch_spectra_f64_fused_1024(pp, in_kind, (int)blocks, s, e->device);

@@ -40,7 +40,9 @@ def main():
         fn(desc, src[i % sets].data_ptr(), frames, dst[i % sets].data_ptr(), stream=stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    probe = None if os.environ.get("R6_NO_PROBE") else eng.clock_probe_start()      # (R6_NO_PROBE=1: no probe wavefront beside the launches)
+    # R6_PROBE=1: a clock-probe wavefront beside the launches (it perturbs kernels that fill a SIMD's registers:
+    # profiles/r06_clock_probe_perturbation.txt); default: none, no shader clock in the line
+    probe = eng.clock_probe_start() if os.environ.get("R6_PROBE") else None
     j0, t0 = ec.joules(), time.time()
     e0.record()
     for i in range(launches):

@@ -12,7 +12,7 @@ WORKLOAD=${2:-batched_1024pt_64k_frames}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --no-cpu-baseline --no-extra --no-energy --workload $WORKLOAD"
+CMD="python3 bench.py --no-cpu-baseline --no-extra --no-energy --no-clock-probe --workload $WORKLOAD"
 # (counter collection serialises kernels: the probe wavefront of bench.py would hold the launches back)
 PMC="python3 bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-extra --no-energy --no-clock-probe --workload $WORKLOAD"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err

@@ -33,8 +33,11 @@ def test_hbm_traffic_is_close_to_algorithmic():
     sys.path.insert(0, ROOT)
     import bench
     t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    # (round 6: every BASELINE configuration in the reference's arithmetic is among them -- configs[1] headline,
+    # configs[2] hann_4096pt_k8_db_f64c_f32o, configs[3] cic8_2048pt_f64 -- from this round's own --pmc passes)
     for name in ("batched_1024pt_64k_frames", "hann_4096pt_k8_db", "cic12_2048pt", "cic8_2048pt",
-                 "batched_1024pt_64k_frames_f64"):
+                 "batched_1024pt_64k_frames_f64", "batched_1024pt_64k_frames_f64c_f32o",
+                 "hann_4096pt_k8_db_f64c_f32o", "cic8_2048pt_f64"):
         n_fft, k_avg, window, output, cic_r, frames = bench.WORKLOADS[name]
         alg = bench.algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, name in bench.F64_WORKLOADS) * frames
         assert 0.97 <= t[name]["bytes_per_launch"] / alg <= 1.03, (name, t[name]["bytes_per_launch"], alg)
@@ -51,3 +54,24 @@ def test_valu_issue_fractions_are_plausible():
         t = json.load(open(os.path.join(ROOT, "profiles", "r03_%s_timed_launches.json" % name)))
         v = bench.valu_issue_frac(name, t["timed_avg_ns"] * 1e-9, 256)
         assert v is not None and lo < v["valu_issue_frac"] < hi, (name, v)
+
+
+def test_round6_profiles_cover_every_baseline_config_in_the_reference_arithmetic():
+    """the fraction of every BASELINE config can be recomputed from THIS round's profiles --
+    per-dispatch average over the timed launches (rocprofv3 --kernel-trace) and the --pmc traffic."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for name, lo, hi in (("batched_1024pt_64k_frames_f64c_f32o", 0.43, 0.52), ("hann_4096pt_k8_db_f64c_f32o", 0.12, 0.16),
+                         ("hann_4096pt_k8_db", 0.25, 0.31), ("cic8_2048pt_f64", 0.65, 0.74)):
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_%s_timed_launches.json" % name)))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r06_%s_pmc.json" % name)))
+        n_fft, k_avg, window, output, cic_r, frames = bench.WORKLOADS[name]
+        alg = bench.algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, name in bench.F64_WORKLOADS) * frames
+        frac = alg / d["timed_avg_ns"] / bench.HBM_PEAK_GBS
+        assert lo < frac < hi, (name, frac)
+        assert d["timed_launches"] == 2000 and d["dropped_first"] == 500
+        assert p["hbm"]["bytes_per_launch"] == t[name]["bytes_per_launch"]
+        # the bench line of the profiled run carries no probe wavefront beside its timed launches
+        assert "sclk_ghz" not in d["bench_line_same_run"]["roofline"]

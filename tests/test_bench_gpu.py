@@ -54,8 +54,14 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
         assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
         assert r["dtype"] == ("int32" if name == "cic8_block_sums" else
                               {"f32": "f32", "f64": "f64", "f64c_f32o": "f64 arithmetic, f32 rows"}[prec])
-        # the shader clock of THIS run's timed launches, measured beside them (rtlws_clock_probe_*)
-        assert 0.5 < roof["sclk_ghz"] < 2.6 and "this run" in roof["sclk_source"]
+        # the shader clock of this run, measured on a leg of its own AFTER the timed region (rtlws_clock_probe_*): the
+        # probe wavefront is never beside the timed launches (round 6: it perturbed them), the leg's own launch time
+        # is in the line and a leg more than 3 % slower than the timed launches is flagged
+        assert 0.5 < roof["sclk_ghz"] < 2.6 and "this run" in roof["sclk_source"] and "WITHOUT" in roof["sclk_source"]
+        assert roof["sclk_leg_avg_launch_us"] > 0 and isinstance(roof["sclk_perturbed"], bool)
+        assert roof["sclk_perturbed"] == (roof["sclk_leg_avg_launch_us"] > 1.03 * roof["avg_launch_us"])
+        if roof["sclk_perturbed"]:
+            assert "valu_issue_frac" not in roof
         if "valu_issue_frac" in roof:                         # (only workloads with a committed instruction count)
             assert "own shader clock" in roof["valu_issue_source"] and 0.0 < roof["valu_issue_frac"] < 1.0   # (small launches: mostly fill and drain)
         n_fft, k_avg, _, output, cic_r, _ = bench.WORKLOADS[name]

@@ -365,7 +365,6 @@ def energy_counter_for(rtlws, device_index):
 
 
 ENERGY_LAUNCHES = 600          # launches of the energy leg (after the timed region, untimed)
-CLOCK_LAUNCHES = 300           # launches of the clock leg (after the energy leg, beside the probe wavefront)
 
 
 def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0):
@@ -434,10 +433,22 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # (No probe wavefront beside the timed launches -- rounds 4-5 had one: it takes registers on one SIMD, and a
-    # kernel that fills a SIMD's registers then has a workgroup that cannot be resident and runs after the others:
-    # +1..3 % on most workloads, +38 % on the 4096-point f64 rows, profiles/r06_clock_probe_perturbation.txt.  The
-    # shader clock is measured on a leg of its own, below.)
+    # The shader clock of THESE launches: two one-wavefront stamp kernels in the launch stream, one before the first
+    # HIP event and one behind the last, each writes s_memtime (shader clocks) and s_memrealtime (100 MHz) and leaves
+    # (include/rtlws_hip.h, rtlws_clock_stamp).  Nothing is resident beside the timed launches -- rounds 4-5 kept a
+    # probe wavefront on a queue of its own there, which round 6 found to cost them +1..7 % (+38 % for kernels that
+    # fill a SIMD's registers; profiles/r06_clock_probe_perturbation.txt).
+    stamps = None
+    if ctx.get("clock_probe", True):
+        stamps = torch.zeros((2, 4), dtype=torch.int64, device=device)
+        try:
+            eng.clock_stamp(stamps[0].data_ptr(), stream=stream)       # (first use: the kernel's code object is loaded)
+            torch.cuda.synchronize()
+        except Exception as ex:                  # an auxiliary measurement: without it the line has no sclk_ghz
+            print("bench.py: clock stamp failed (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
+            stamps = None
+    if stamps is not None:                       # (ahead of the host clock: ~3 us of device time before the first launch)
+        L.rtlws_clock_stamp(eng.h, stamps[0].data_ptr(), stream)
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
     tA = time.perf_counter()
@@ -445,6 +456,8 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         step(i)
     tB = time.perf_counter()
     L.rtlws_event_record(ev1, eng.h, stream)
+    if stamps is not None:
+        L.rtlws_clock_stamp(eng.h, stamps[1].data_ptr(), stream)
     tC = time.perf_counter()
     tD = time.perf_counter()
     torch.cuda.synchronize()
@@ -478,33 +491,11 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
                           "source": "rocm_smi rsmi_dev_energy_count_get of the GPU at this bus id around %d further "
                                     "launches after the timed region (package energy accumulator; not part of "
                                     "`value`)" % ENERGY_LAUNCHES}
-    # clock leg (after the clock has stopped, after the energy leg): CLOCK_LAUNCHES more launches of the same step with
-    # ONE sleeping wavefront on a queue of its own beside them, which reads the shader-clock and 100 MHz counters when
-    # the leg starts and when the device itself tells it to leave (a write-value packet behind the last launch):
-    # the clock the governor gives this step (include/rtlws_hip.h, rtlws_clock_probe_*).  The probe costs the kernel
-    # registers on one SIMD: the leg's own launch time is in the line, and where it is more than 3 % over the timed
-    # launches' the clock is reported as that of a PERTURBED run and nothing is derived from it.
-    sclk_ghz, probe_s, clock_leg_us = None, None, None
-    if ctx.get("clock_probe", True):
-        try:
-            probe = eng.clock_probe_start()
-            evc0, evc1 = L.rtlws_event_create(), L.rtlws_event_create()
-            L.rtlws_event_record(evc0, eng.h, stream)
-            for i in range(CLOCK_LAUNCHES):
-                step(i)
-            L.rtlws_event_record(evc1, eng.h, stream)
-            try:
-                eng.clock_probe_signal_on_stream(probe, stream)
-            except Exception as ex:
-                print("bench.py: clock probe signal failed (%s); stopping it from the host" % ex, file=sys.stderr)
-                eng.clock_probe_signal(probe)
-            torch.cuda.synchronize()
-            sclk_ghz, probe_s = eng.clock_probe_stop(probe)
-            clock_leg_us = 1e3 * L.rtlws_event_elapsed_ms(evc0, evc1) / CLOCK_LAUNCHES
-            L.rtlws_event_destroy(evc0)
-            L.rtlws_event_destroy(evc1)
-        except Exception as ex:                  # an auxiliary measurement: without it the line has no sclk_ghz
-            print("bench.py: clock leg failed (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
+    sclk_ghz, probe_s, stamp_xcc = None, None, None
+    if stamps is not None:
+        st = stamps.cpu().numpy()
+        sclk_ghz, probe_s = eng.clock_from_stamps(st[0], st[1])
+        stamp_xcc = [int(st[0][2]), int(st[1][2])]
     per_rank_sclk = gather_ranks(torch, dist, sclk_ghz or 0.0, ctx.get("reduce_device", device))
     rdev = ctx.get("reduce_device", device)
     elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], rdev)
@@ -575,20 +566,17 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         if energy is not None:
             result["roofline"]["energy"] = energy
         if sclk_ghz:
-            perturbed = clock_leg_us is not None and clock_leg_us > 1.03 * 1e6 * avg_launch_s
             result["roofline"]["sclk_ghz"] = sclk_ghz
-            result["roofline"]["sclk_leg_avg_launch_us"] = clock_leg_us
-            result["roofline"]["sclk_perturbed"] = perturbed
             result["roofline"]["sclk_source"] = (
-                "d(s_memtime) / d(s_memrealtime) x 100 MHz of a probe wavefront resident beside %d further launches of "
-                "the same step after the timed region and the energy leg (%.1f ms, this run); the timed launches run "
-                "WITHOUT it%s" % (CLOCK_LAUNCHES, 1e3 * probe_s,
-                                  ": here the probe's registers cost the kernel a workgroup's residency (the leg's launches "
-                                  "are more than 3 % slower than the timed ones), so this is the clock of a PERTURBED run"
-                                  if perturbed else ""))
-            vf = None if perturbed else valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
+                "d(s_memtime) / d(s_memrealtime) x 100 MHz between two one-wavefront stamp kernels in the launch stream, "
+                "one before and one behind the timed launches (%.3f ms apart, both on XCC %d, this run); nothing is "
+                "resident beside the timed launches" % (1e3 * probe_s, stamp_xcc[0]))
+            vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
             if vf is not None:
                 result["roofline"].update(vf)
+        elif stamp_xcc is not None:
+            result["roofline"]["sclk_source"] = ("no shader clock: the two stamp kernels ran on XCCs %d and %d, whose "
+                                                 "counters are not one clock" % tuple(stamp_xcc))
         if world > 1:
             # every rank's own figures, so a scaling loss is visible in this one line
             result["per_rank"] = {"ranks": ranks,
@@ -1048,7 +1036,7 @@ def main(argv=None):
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration (roofline.box)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy leg after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
-                    help="no clock leg (rocprofv3 --pmc serialises kernels: its launches would wait for the probe)")
+                    help="no clock stamps around the timed launches (two more dispatches in a profiler's trace)")
     ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 

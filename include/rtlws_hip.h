@@ -292,7 +292,20 @@ int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, 
 int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float* d_prev_in,
                    float* d_prev_out, float* d_out, void* stream);
 
-/* ---- measurement: the shader clock DURING a timed region -------------------------------
+/* ---- measurement: the shader clock OVER a timed region ---------------------------------
+ * rtlws_clock_stamp enqueues ONE wavefront on `stream` that writes {s_memtime (shader clocks), s_memrealtime (100 MHz),
+ * XCC_ID, HW_ID} to d_out4 -- device memory, four 64-bit words, 8-byte aligned -- and leaves.  Two stamps in one
+ * stream, one before and one after the launches being timed, give the clock the package power governor gave those
+ * launches: (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz, provided both stamps ran on the same XCC
+ * (word 2: the counter is the XCC's own; a one-workgroup launch lands on the same one in practice).  Nothing is
+ * resident beside the timed launches: bench.py's roofline.sclk_ghz and valu_issue_frac use this since round 6.
+ * 0 / -1 / -3. */
+int rtlws_clock_stamp(rtlws_engine* e, unsigned long long* d_out4, void* stream);
+
+/* The earlier instrument, kept for kernels with registers to spare and for the record of what it costs
+ * (profiles/r06_clock_probe_perturbation.txt: +1 .. 7 % on the launches it sits beside, +38 % on kernels that fill a
+ * SIMD's registers -- one of their workgroups then cannot be resident -- because it IS resident, on a hardware queue
+ * of its own):
  * rtlws_clock_probe_start puts ONE wavefront on a queue of its own beside whatever the caller
  * enqueues next; it records s_memtime (shader clocks) and s_memrealtime (100 MHz) when it starts and
  * again when told to leave (rtlws_clock_probe_signal: returns at once; rtlws_clock_probe_stop:

@@ -254,6 +254,26 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsign
     }
 }
 
+// ---- shader-clock stamp (measurement infrastructure; include/rtlws_hip.h, rtlws_clock_stamp) ----
+// One wavefront that writes the two hardware counters and where it ran, and leaves.  Two of them in one stream,
+// around the launches being timed, bracket those launches with NOTHING resident beside them (the probe above takes
+// registers and a second hardware queue: round 6 measured what that costs the launches it sits beside).
+__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* out)
+{
+    if (threadIdx.x == 0) {
+        out[0] = clock64();                                            // s_memtime: shader clocks
+        out[1] = wall_clock64();                                       // s_memrealtime: 100 MHz
+        out[2] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;     // XCC_ID: the counter is the XCC's own
+        out[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID
+    }
+}
+
+hipError_t launch_clock_stamp(unsigned long long* d_out4, hipStream_t st)
+{
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, st, d_out4);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(const int* stop_flag, unsigned long long* out, int max_polls, hipStream_t st)
 {
     // 10 s of the 100 MHz counter, whatever a poll costs

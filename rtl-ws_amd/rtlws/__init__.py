@@ -77,7 +77,7 @@ HIP_SYMBOLS = [
     "rtlws_welch_accumulate_f64", "rtlws_welch_finish_f64",
     "rtlws_queue_create", "rtlws_queue_destroy", "rtlws_queue_wait_event", "rtlws_event_create_blocking",
     "rtlws_clock_probe_start", "rtlws_clock_probe_signal", "rtlws_clock_probe_signal_on_stream",
-    "rtlws_clock_probe_stop",
+    "rtlws_clock_probe_stop", "rtlws_clock_stamp",
 ]
 AUDIO_SYMBOLS = ["audio_init", "audio_new_audio_available", "audio_get_audio_payload",
                  "audio_fm_demodulator", "audio_close"]
@@ -179,6 +179,7 @@ def hip_lib():
         L.rtlws_payload_from_sums.argtypes = [vp, vp, i, i, i, vp, vp]
         L.rtlws_fm_demod.argtypes = [vp, vp, l, vp, vp, vp, vp]
         L.rtlws_copy_d2d.argtypes = [vp, vp, vp, sz, vp]
+        L.rtlws_clock_stamp.argtypes = [vp, vp, vp]
         L.rtlws_clock_probe_start.argtypes = [vp]
         L.rtlws_clock_probe_start.restype = vp
         L.rtlws_clock_probe_signal.argtypes = [vp]
@@ -343,6 +344,21 @@ class Engine:
 
     def sync(self, stream=None):
         self._chk(hip_lib().rtlws_stream_sync(self.h, stream), "sync")
+
+    def clock_stamp(self, d_out4, stream=None):
+        """One wavefront on `stream` writes {shader clocks, 100 MHz ticks, XCC_ID, HW_ID} to the device pointer d_out4."""
+        self._chk(hip_lib().rtlws_clock_stamp(self.h, self._ptr(d_out4), stream), "rtlws_clock_stamp")
+
+    @staticmethod
+    def clock_from_stamps(s0, s1):
+        """(sclk_ghz, seconds) between two stamps (sequences of four integers), or (None, seconds) when they ran on
+        different XCCs (the shader-clock counter is the XCC's own) or the interval is empty."""
+        ticks = int(s1[1]) - int(s0[1])
+        if ticks <= 0:
+            return None, 0.0
+        if int(s0[2]) != int(s1[2]):
+            return None, ticks * 1e-8
+        return (int(s1[0]) - int(s0[0])) / (ticks * 10.0), ticks * 1e-8
 
     def clock_probe_start(self):
         """A wavefront beside the next launches that measures the shader clock they run at."""

@@ -364,7 +364,8 @@ def energy_counter_for(rtlws, device_index):
         return None
 
 
-ENERGY_LAUNCHES = 600          # launches of the energy leg (after the timed region, untimed)
+ENERGY_LAUNCHES = 600          # launches of the leg behind the timed region (energy accumulator, clock stamps)
+CLOCK_SLOTS = 2048             # one-wavefront workgroups of a stamp launch: two per SIMD of an MI355X
 
 
 def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline=False, cpu_budget_scale=1.0):
@@ -433,22 +434,10 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # The shader clock of THESE launches: two one-wavefront stamp kernels in the launch stream, one before the first
-    # HIP event and one behind the last, each writes s_memtime (shader clocks) and s_memrealtime (100 MHz) and leaves
-    # (include/rtlws_hip.h, rtlws_clock_stamp).  Nothing is resident beside the timed launches -- rounds 4-5 kept a
-    # probe wavefront on a queue of its own there, which round 6 found to cost them +1..7 % (+38 % for kernels that
-    # fill a SIMD's registers; profiles/r06_clock_probe_perturbation.txt).
-    stamps = None
-    if ctx.get("clock_probe", True):
-        stamps = torch.zeros((2, 4), dtype=torch.int64, device=device)
-        try:
-            eng.clock_stamp(stamps[0].data_ptr(), stream=stream)       # (first use: the kernel's code object is loaded)
-            torch.cuda.synchronize()
-        except Exception as ex:                  # an auxiliary measurement: without it the line has no sclk_ghz
-            print("bench.py: clock stamp failed (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
-            stamps = None
-    if stamps is not None:                       # (ahead of the host clock: ~3 us of device time before the first launch)
-        L.rtlws_clock_stamp(eng.h, stamps[0].data_ptr(), stream)
+    # (Nothing but the launches between the two HIP events, and nothing resident beside them: rounds 4-5 kept a
+    # clock-probe wavefront on a queue of its own there, which round 6 found to cost the launches +1..7 % -- +38 %
+    # for kernels that fill a SIMD's registers; profiles/r06_clock_probe_perturbation.txt.  The shader clock is
+    # measured on the leg behind the timed region, below.)
     t0 = time.perf_counter()
     L.rtlws_event_record(ev0, eng.h, stream)
     tA = time.perf_counter()
@@ -456,8 +445,6 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
         step(i)
     tB = time.perf_counter()
     L.rtlws_event_record(ev1, eng.h, stream)
-    if stamps is not None:
-        L.rtlws_clock_stamp(eng.h, stamps[1].data_ptr(), stream)
     tC = time.perf_counter()
     tD = time.perf_counter()
     torch.cuda.synchronize()
@@ -472,30 +459,52 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
     ev_ms = L.rtlws_event_elapsed_ms(ev0, ev1)
     L.rtlws_event_destroy(ev0)
     L.rtlws_event_destroy(ev1)
-    # energy leg (one-GPU jobs; after the clock has stopped): the package energy accumulator around
-    # ENERGY_LAUNCHES more launches of the same step -- joules per launch and the power they ran at
-    energy = None
+    # The leg behind the timed region (after the clock has stopped, outside `value`): ENERGY_LAUNCHES more launches
+    # of the same step, in the same steady state, with
+    #  * the package energy accumulator of this device read before and after (one-GPU jobs) -- joules per launch and
+    #    the watts they ran at;
+    #  * two stamp launches in the stream around them (include/rtlws_hip.h, rtlws_clock_stamp: CLOCK_SLOTS one-wavefront
+    #    workgroups that each write s_memtime, s_memrealtime and the place they ran at, and leave), paired by place:
+    #    the shader clock the governor gives this step.  Nothing is resident beside the launches.
+    energy, sclk_ghz, probe_s, stamp_places, leg_us = None, None, None, 0, None
     ec = ctx.get("energy_counter") if (world == 1 and ctx.get("energy", True)) else None
-    if ec is not None:
-        j0 = ec.joules()
-        if j0 is not None:
-            tq0 = time.perf_counter()
-            for i in range(ENERGY_LAUNCHES):
-                step(i)
-            torch.cuda.synchronize()
-            tq1 = time.perf_counter()
-            j1 = ec.joules()
-            if j1 is not None and j1 > j0:
-                energy = {"mj_per_launch": 1e3 * (j1 - j0) / ENERGY_LAUNCHES, "watts": (j1 - j0) / (tq1 - tq0),
-                          "launches": ENERGY_LAUNCHES, "bus_id": ec.bus_id, "rsmi_index": ec.index,
-                          "source": "rocm_smi rsmi_dev_energy_count_get of the GPU at this bus id around %d further "
-                                    "launches after the timed region (package energy accumulator; not part of "
-                                    "`value`)" % ENERGY_LAUNCHES}
-    sclk_ghz, probe_s, stamp_xcc = None, None, None
-    if stamps is not None:
-        st = stamps.cpu().numpy()
-        sclk_ghz, probe_s = eng.clock_from_stamps(st[0], st[1])
-        stamp_xcc = [int(st[0][2]), int(st[1][2])]
+    want_clock = ctx.get("clock_probe", True)
+    if ec is not None or want_clock:
+        stamps = None
+        if want_clock:
+            try:
+                stamps = torch.zeros((2, CLOCK_SLOTS, 4), dtype=torch.int64, device=device)
+                eng.clock_stamp(stamps[0].data_ptr(), CLOCK_SLOTS, stream=stream)      # (first use loads the code object)
+                torch.cuda.synchronize()
+            except Exception as ex:              # an auxiliary measurement: without it the line has no sclk_ghz
+                print("bench.py: clock stamp failed (%s); continuing without sclk_ghz" % ex, file=sys.stderr)
+                stamps = None
+        j0 = ec.joules() if ec is not None else None
+        evl0, evl1 = L.rtlws_event_create(), L.rtlws_event_create()
+        tq0 = time.perf_counter()
+        if stamps is not None:
+            L.rtlws_clock_stamp(eng.h, stamps[0].data_ptr(), CLOCK_SLOTS, stream)
+        L.rtlws_event_record(evl0, eng.h, stream)
+        for i in range(ENERGY_LAUNCHES):
+            step(i)
+        L.rtlws_event_record(evl1, eng.h, stream)
+        if stamps is not None:
+            L.rtlws_clock_stamp(eng.h, stamps[1].data_ptr(), CLOCK_SLOTS, stream)
+        torch.cuda.synchronize()
+        tq1 = time.perf_counter()
+        j1 = ec.joules() if ec is not None else None
+        leg_us = 1e3 * L.rtlws_event_elapsed_ms(evl0, evl1) / ENERGY_LAUNCHES
+        L.rtlws_event_destroy(evl0)
+        L.rtlws_event_destroy(evl1)
+        if j0 is not None and j1 is not None and j1 > j0:
+            energy = {"mj_per_launch": 1e3 * (j1 - j0) / ENERGY_LAUNCHES, "watts": (j1 - j0) / (tq1 - tq0),
+                      "launches": ENERGY_LAUNCHES, "avg_launch_us": leg_us, "bus_id": ec.bus_id, "rsmi_index": ec.index,
+                      "source": "rocm_smi rsmi_dev_energy_count_get of the GPU at this bus id around %d further "
+                                "launches after the timed region (package energy accumulator; not part of "
+                                "`value`)" % ENERGY_LAUNCHES}
+        if stamps is not None:
+            st = stamps.cpu().numpy()
+            sclk_ghz, probe_s, stamp_places = eng.clock_from_stamps(st[0], st[1])
     per_rank_sclk = gather_ranks(torch, dist, sclk_ghz or 0.0, ctx.get("reduce_device", device))
     rdev = ctx.get("reduce_device", device)
     elapsed, ev_ms_max = max_over_ranks(torch, dist, [elapsed, ev_ms], rdev)
@@ -567,16 +576,14 @@ def run_workload(ctx, name, steps, warmup, sets, frames_override=0, cpu_baseline
             result["roofline"]["energy"] = energy
         if sclk_ghz:
             result["roofline"]["sclk_ghz"] = sclk_ghz
+            result["roofline"]["sclk_leg_avg_launch_us"] = leg_us
             result["roofline"]["sclk_source"] = (
-                "d(s_memtime) / d(s_memrealtime) x 100 MHz between two one-wavefront stamp kernels in the launch stream, "
-                "one before and one behind the timed launches (%.3f ms apart, both on XCC %d, this run); nothing is "
-                "resident beside the timed launches" % (1e3 * probe_s, stamp_xcc[0]))
+                "median over %d places (XCC, SE, SH, CU, SIMD) of d(s_memtime) / d(s_memrealtime) x 100 MHz between two stamp "
+                "launches in the launch stream around %d further launches of the same step behind the timed region "
+                "(%.3f ms, this run); nothing is resident beside the launches" % (stamp_places, ENERGY_LAUNCHES, 1e3 * probe_s))
             vf = valu_issue_frac(name, avg_launch_s, ctx.get("cu_count", 256), sclk_ghz, frames)
             if vf is not None:
                 result["roofline"].update(vf)
-        elif stamp_xcc is not None:
-            result["roofline"]["sclk_source"] = ("no shader clock: the two stamp kernels ran on XCCs %d and %d, whose "
-                                                 "counters are not one clock" % tuple(stamp_xcc))
         if world > 1:
             # every rank's own figures, so a scaling loss is visible in this one line
             result["per_rank"] = {"ranks": ranks,
@@ -1036,7 +1043,7 @@ def main(argv=None):
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration (roofline.box)")
     ap.add_argument("--no-energy", action="store_true", help="skip the energy leg after the timed region")
     ap.add_argument("--no-clock-probe", action="store_true",
-                    help="no clock stamps around the timed launches (two more dispatches in a profiler's trace)")
+                    help="no clock stamps around the leg behind the timed region (with --no-energy: no such leg at all)")
     ap.add_argument("--plumbing-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 

@@ -292,15 +292,15 @@ int rtlws_halfband(rtlws_engine* e, const float* d_x, float* d_y, long out_len, 
 int rtlws_fm_demod(rtlws_engine* e, const void* d_iq_cs32, long len, const float* d_prev_in,
                    float* d_prev_out, float* d_out, void* stream);
 
-/* ---- measurement: the shader clock OVER a timed region ---------------------------------
- * rtlws_clock_stamp enqueues ONE wavefront on `stream` that writes {s_memtime (shader clocks), s_memrealtime (100 MHz),
- * XCC_ID, HW_ID} to d_out4 -- device memory, four 64-bit words, 8-byte aligned -- and leaves.  Two stamps in one
- * stream, one before and one after the launches being timed, give the clock the package power governor gave those
- * launches: (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz, provided both stamps ran on the same XCC
- * (word 2: the counter is the XCC's own; a one-workgroup launch lands on the same one in practice).  Nothing is
- * resident beside the timed launches: bench.py's roofline.sclk_ghz and valu_issue_frac use this since round 6.
- * 0 / -1 / -3. */
-int rtlws_clock_stamp(rtlws_engine* e, unsigned long long* d_out4, void* stream);
+/* ---- measurement: the shader clock OVER a series of launches ----------------------------
+ * rtlws_clock_stamp enqueues `slots` one-wavefront workgroups on `stream`; workgroup i writes {s_memtime (shader
+ * clocks), s_memrealtime (100 MHz), place, 0x5354414d50} to d_out[4 i .. 4 i + 3] -- device memory, 8-byte aligned --
+ * and leaves; place = XCC_ID << 16 | HW_ID & 0xff30 (SE, SH, CU, SIMD).  s_memtime is a counter of the place it is read
+ * at, so two such launches in one stream, before and after the launches being measured, are paired BY PLACE:
+ * (memtime1 - memtime0) / (memrealtime1 - memrealtime0) x 100 MHz per place is the clock the package power governor
+ * gave that interval (take the median; 2 048 slots cover the 1 024 SIMDs of an MI355X).  Nothing is resident beside
+ * the launches in between: bench.py's roofline.sclk_ghz uses this since round 6.  0 / -1 / -3. */
+int rtlws_clock_stamp(rtlws_engine* e, unsigned long long* d_out, int slots, void* stream);
 
 /* The earlier instrument, kept for kernels with registers to spare and for the record of what it costs
  * (profiles/r06_clock_probe_perturbation.txt: +1 .. 7 % on the launches it sits beside, +38 % on kernels that fill a

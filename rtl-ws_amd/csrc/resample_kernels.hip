@@ -255,22 +255,28 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(const int* stop, unsign
 }
 
 // ---- shader-clock stamp (measurement infrastructure; include/rtlws_hip.h, rtlws_clock_stamp) ----
-// One wavefront that writes the two hardware counters and where it ran, and leaves.  Two of them in one stream,
-// around the launches being timed, bracket those launches with NOTHING resident beside them (the probe above takes
-// registers and a second hardware queue: round 6 measured what that costs the launches it sits beside).
+// `slots` one-wavefront workgroups that each write the two hardware counters and WHERE they ran, and leave.  Two such
+// launches in one stream, around the launches being measured, bracket them with NOTHING resident beside them (the
+// probe above takes registers and a second hardware queue: round 6 measured what that costs the launches it sits
+// beside).  s_memtime is a counter of the place it is read at (two one-wavefront stamps on different CUs differ by
+// arbitrary offsets), so the host pairs the records of the two launches BY PLACE -- XCC, SE, SH, CU, SIMD -- and
+// takes d(memtime) / d(memrealtime) per place.
 __global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* out)
 {
     if (threadIdx.x == 0) {
-        out[0] = clock64();                                            // s_memtime: shader clocks
-        out[1] = wall_clock64();                                       // s_memrealtime: 100 MHz
-        out[2] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;     // XCC_ID: the counter is the XCC's own
-        out[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID
+        unsigned long long* o = out + 4 * (size_t)blockIdx.x;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u; // XCC_ID
+        o[0] = clock64();                                            // s_memtime: shader clocks
+        o[1] = wall_clock64();                                       // s_memrealtime: 100 MHz
+        o[2] = ((unsigned long long)xcc << 16) | (hw & 0xff30u);     // the place
+        o[3] = 0x5354414d50ull;                                      // written
     }
 }
 
-hipError_t launch_clock_stamp(unsigned long long* d_out4, hipStream_t st)
+hipError_t launch_clock_stamp(unsigned long long* d_out, int slots, hipStream_t st)
 {
-    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, st, d_out4);
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(slots), dim3(64), 0, st, d_out);
     return hipGetLastError();
 }
 

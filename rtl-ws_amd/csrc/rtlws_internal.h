@@ -236,7 +236,7 @@ hipError_t launch_halfband(const float* d_x, float* d_y, long out_len, hipStream
 hipError_t launch_fm_demod(const void* d_iq, long len, const float* d_prev_in, float* d_prev_out,
                            float* d_out, hipStream_t, int cus);
 hipError_t launch_clock_probe(const int* stop_flag, unsigned long long* out, int max_polls, hipStream_t);
-hipError_t launch_clock_stamp(unsigned long long* d_out4, hipStream_t);
+hipError_t launch_clock_stamp(unsigned long long* d_out, int slots, hipStream_t);
 hipError_t launch_payload(const float* d_sums, int n, float lin_gain, uint8_t* d_out, hipStream_t);
 hipError_t launch_spectra_f64(const SpectraParamsF64&, int in_kind, hipStream_t, int device);
 hipError_t launch_welch_accumulate(double* d_acc, const double* d_part, int n, long frames_end, double* d_b, hipStream_t);

@@ -1029,16 +1029,16 @@ struct rtlws_clock_probe {
     unsigned long long* out = nullptr;  // pinned: {shader clocks, 100 MHz ticks, polls, resident flag}
 };
 
-int rtlws_clock_stamp(rtlws_engine* e, unsigned long long* d_out4, void* stream)
+int rtlws_clock_stamp(rtlws_engine* e, unsigned long long* d_out, int slots, void* stream)
 {
     g_err.clear();
     NEED_ENGINE(e, -1);
-    if (!d_out4 || (reinterpret_cast<uintptr_t>(d_out4) & 7u)) {
-        g_err = "rtlws_clock_stamp: d_out4 must be an 8-byte aligned device pointer to four 64-bit words";
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 7u) || slots < 1 || slots > 65536) {
+        g_err = "rtlws_clock_stamp: d_out must be an 8-byte aligned device pointer to slots x 4 64-bit words, 1 <= slots <= 65536";
         return -1;
     }
     HIP_TRY(hipSetDevice(e->device), -3);
-    const hipError_t err = rtlws::launch_clock_stamp(d_out4, pick_stream(e, stream));
+    const hipError_t err = rtlws::launch_clock_stamp(d_out, slots, pick_stream(e, stream));
     if (err != hipSuccess) { set_err("clock stamp kernel launch", err); return -3; }
     return 0;
 }

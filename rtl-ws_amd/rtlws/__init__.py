@@ -179,7 +179,7 @@ def hip_lib():
         L.rtlws_payload_from_sums.argtypes = [vp, vp, i, i, i, vp, vp]
         L.rtlws_fm_demod.argtypes = [vp, vp, l, vp, vp, vp, vp]
         L.rtlws_copy_d2d.argtypes = [vp, vp, vp, sz, vp]
-        L.rtlws_clock_stamp.argtypes = [vp, vp, vp]
+        L.rtlws_clock_stamp.argtypes = [vp, vp, C.c_int, vp]
         L.rtlws_clock_probe_start.argtypes = [vp]
         L.rtlws_clock_probe_start.restype = vp
         L.rtlws_clock_probe_signal.argtypes = [vp]
@@ -345,20 +345,33 @@ class Engine:
     def sync(self, stream=None):
         self._chk(hip_lib().rtlws_stream_sync(self.h, stream), "sync")
 
-    def clock_stamp(self, d_out4, stream=None):
-        """One wavefront on `stream` writes {shader clocks, 100 MHz ticks, XCC_ID, HW_ID} to the device pointer d_out4."""
-        self._chk(hip_lib().rtlws_clock_stamp(self.h, self._ptr(d_out4), stream), "rtlws_clock_stamp")
+    def clock_stamp(self, d_out, slots, stream=None):
+        """`slots` one-wavefront workgroups on `stream` write {shader clocks, 100 MHz ticks, place, magic} to the
+        device pointer d_out (slots x 4 64-bit words)."""
+        self._chk(hip_lib().rtlws_clock_stamp(self.h, self._ptr(d_out), int(slots), stream), "rtlws_clock_stamp")
 
     @staticmethod
-    def clock_from_stamps(s0, s1):
-        """(sclk_ghz, seconds) between two stamps (sequences of four integers), or (None, seconds) when they ran on
-        different XCCs (the shader-clock counter is the XCC's own) or the interval is empty."""
-        ticks = int(s1[1]) - int(s0[1])
-        if ticks <= 0:
-            return None, 0.0
-        if int(s0[2]) != int(s1[2]):
-            return None, ticks * 1e-8
-        return (int(s1[0]) - int(s0[0])) / (ticks * 10.0), ticks * 1e-8
+    def clock_from_stamps(a0, a1):
+        """(sclk_ghz, seconds, places) between two stamp launches (arrays of shape [slots, 4]): the records are paired
+        by place -- s_memtime is a counter of the place it is read at -- and the median of d(memtime) / d(memrealtime)
+        x 100 MHz over the places both launches reached is returned, with the median interval and the number of
+        places; (None, 0.0, 0) when no place is common or the interval is empty."""
+        first = {}
+        for mt, rt, place, magic in np.asarray(a0).astype(np.int64).tolist():
+            if magic == 0x5354414d50 and place not in first:
+                first[place] = (mt, rt)
+        ghz, secs = [], []
+        seen = set()
+        for mt, rt, place, magic in np.asarray(a1).astype(np.int64).tolist():
+            if magic == 0x5354414d50 and place in first and place not in seen:
+                seen.add(place)
+                dmt, drt = mt - first[place][0], rt - first[place][1]
+                if drt > 0 and dmt > 0:
+                    ghz.append(dmt / (drt * 10.0))
+                    secs.append(drt * 1e-8)
+        if not ghz:
+            return None, 0.0, 0
+        return float(np.median(ghz)), float(np.median(secs)), len(ghz)
 
     def clock_probe_start(self):
         """A wavefront beside the next launches that measures the shader clock they run at."""

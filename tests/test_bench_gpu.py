@@ -54,10 +54,11 @@ def test_run_workload_parity_is_finite_bounded_and_repeatable(ctx, name, monkeyp
         assert roof["frac_wall"] <= roof["frac"] * 1.05       # the wall clock contains the events' span
         assert r["dtype"] == ("int32" if name == "cic8_block_sums" else
                               {"f32": "f32", "f64": "f64", "f64c_f32o": "f64 arithmetic, f32 rows"}[prec])
-        # the shader clock of THIS run's timed launches, between two stamp kernels in the launch stream
-        # (rtlws_clock_stamp): nothing is resident beside the timed launches (round 6: the probe wavefront of rounds
-        # 4-5 perturbed them)
+        # the shader clock of this step, between two stamp launches around the leg behind the timed region
+        # (rtlws_clock_stamp): nothing is resident beside the launches (round 6: the probe wavefront of rounds 4-5
+        # perturbed the timed launches it sat beside)
         assert 0.5 < roof["sclk_ghz"] < 2.6 and "this run" in roof["sclk_source"] and "nothing is resident" in roof["sclk_source"]
+        assert roof["sclk_leg_avg_launch_us"] > 0
         if "valu_issue_frac" in roof:                         # (only workloads with a committed instruction count)
             assert "own shader clock" in roof["valu_issue_source"] and 0.0 < roof["valu_issue_frac"] < 1.0   # (small launches: mostly fill and drain)
         n_fft, k_avg, _, output, cic_r, _ = bench.WORKLOADS[name]
@@ -162,34 +163,39 @@ def test_two_ranks_rehearsal_on_one_gpu():
 
 
 def test_clock_stamps_bracket_a_plausible_clock(ctx):
-    """rtlws_clock_stamp: two one-wavefront stamps in one stream around a series of launches give a shader clock in
-    the chip's range over an interval as long as the launches; both stamps on one XCC; bad arguments refused."""
+    """rtlws_clock_stamp: two stamp launches in one stream around a series of launches, paired by place (s_memtime is
+    a counter of the place it is read at), give a shader clock in the chip's range over an interval as long as the
+    launches, from most of the chip's SIMDs; bad arguments are refused."""
     import torch
-    import bench
     eng, built = ctx["eng"], ctx["rtlws"]
     dev = ctx["device"]
     stream = built.torch_stream_handle()
     iq = torch.randint(0, 256, (4096, 1024, 2), dtype=torch.uint8, device=dev)
     out = torch.empty((4096, 1024), dtype=torch.float32, device=dev)
     desc = built.make_desc(1024)
-    st = torch.zeros((2, 4), dtype=torch.int64, device=dev)
-    eng.clock_stamp(st[0].data_ptr(), stream=stream)
+    slots = 2048
+    st = torch.zeros((2, slots, 4), dtype=torch.int64, device=dev)
+    eng.clock_stamp(st[0].data_ptr(), slots, stream=stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(200):
         eng.spectra_batch(desc, iq.data_ptr(), 4096, out.data_ptr(), stream=stream)
     e1.record()
-    eng.clock_stamp(st[1].data_ptr(), stream=stream)
+    eng.clock_stamp(st[1].data_ptr(), slots, stream=stream)
     torch.cuda.synchronize()
     s = st.cpu().numpy()
-    ghz, secs = eng.clock_from_stamps(s[0], s[1])
-    assert s[0][2] == s[1][2] and ghz is not None and 0.5 < ghz < 2.6
+    assert (s[:, :, 3] == 0x5354414d50).all()                       # every slot written, both launches
+    ghz, secs, places = eng.clock_from_stamps(s[0], s[1])
+    assert ghz is not None and 0.5 < ghz < 2.6, ghz
+    assert places >= 4 * ctx["cu_count"] // 2                        # at least half of the SIMDs reached by both launches
     assert 0.9 * e0.elapsed_time(e1) * 1e-3 <= secs <= 1.5 * e0.elapsed_time(e1) * 1e-3 + 1e-3
-    assert eng.clock_from_stamps([100, 50, 0, 0], [300, 50, 0, 0]) == (None, 0.0)                 # empty interval
-    assert eng.clock_from_stamps([100, 50, 0, 0], [300, 150, 1, 0])[0] is None                      # two XCCs
-    assert eng.clock_from_stamps([0, 0, 3, 0], [2000, 100, 3, 0]) == (2.0, 1e-6)
+    M = 0x5354414d50
+    assert eng.clock_from_stamps([[100, 50, 7, M]], [[300, 50, 7, M]]) == (None, 0.0, 0)            # empty interval
+    assert eng.clock_from_stamps([[100, 50, 7, M]], [[300, 150, 8, M]]) == (None, 0.0, 0)           # no common place
+    assert eng.clock_from_stamps([[0, 0, 3, M], [5, 0, 4, 0]], [[2000, 100, 3, M]]) == (2.0, 1e-6, 1)
     L = built.hip_lib()
-    assert L.rtlws_clock_stamp(eng.h, None, None) == -1 and L.rtlws_clock_stamp(eng.h, st[0].data_ptr() + 4, None) == -1
+    assert L.rtlws_clock_stamp(eng.h, None, 4, None) == -1
+    assert L.rtlws_clock_stamp(eng.h, st[0].data_ptr() + 4, 4, None) == -1 and L.rtlws_clock_stamp(eng.h, st[0].data_ptr(), 0, None) == -1
 
 
 def test_clock_probe_measures_a_plausible_clock_and_always_leaves(ctx):

@@ -44,21 +44,22 @@ def main():
     # them).  R6_PROBE=1: the clock-probe wavefront of rounds 4-5 beside the launches instead -- it perturbs them, which
     # is what profiles/r06_clock_probe_perturbation.txt used it to show
     probe = eng.clock_probe_start() if os.environ.get("R6_PROBE") else None
-    stamps = torch.zeros((2, 4), dtype=torch.int64, device=dev)
-    eng.clock_stamp(stamps[0].data_ptr(), stream=stream)
+    slots = 2048
+    stamps = torch.zeros((2, slots, 4), dtype=torch.int64, device=dev)
+    eng.clock_stamp(stamps[0].data_ptr(), slots, stream=stream)
     torch.cuda.synchronize()
     j0, t0 = ec.joules(), time.time()
-    eng.clock_stamp(stamps[0].data_ptr(), stream=stream)
+    eng.clock_stamp(stamps[0].data_ptr(), slots, stream=stream)
     e0.record()
     for i in range(launches):
         fn(desc, src[i % sets].data_ptr(), frames, dst[i % sets].data_ptr(), stream=stream)
     e1.record()
-    eng.clock_stamp(stamps[1].data_ptr(), stream=stream)
+    eng.clock_stamp(stamps[1].data_ptr(), slots, stream=stream)
     if probe is not None:
         eng.clock_probe_signal_on_stream(probe, stream)
     torch.cuda.synchronize()
     j1, t1 = ec.joules(), time.time()
-    sclk, _ = eng.clock_probe_stop(probe) if probe is not None else eng.clock_from_stamps(*stamps.cpu().numpy())
+    sclk = eng.clock_probe_stop(probe)[0] if probe is not None else eng.clock_from_stamps(*stamps.cpu().numpy())[0]
     us = e0.elapsed_time(e1) * 1e3 / launches
     byt = bench.algorithmic_bytes_per_frame(n_fft, k_avg, cic_r, output, prec == "f64") * frames
     print("%-32s %-14s launches %d: %.2f us per launch (events) = %.4f of 8 TB/s, %.1f mJ per launch, %.0f W over %.2f s, "

@@ -43,11 +43,11 @@ def main():
     # the shader clock: two stamp kernels in the stream around the launches (rtlws_clock_stamp; nothing resident beside
     # them).  R6_PROBE=1: the clock-probe wavefront of rounds 4-5 beside the launches instead -- it perturbs them, which
     # is what profiles/r06_clock_probe_perturbation.txt used it to show
-    probe = eng.clock_probe_start() if os.environ.get("R6_PROBE") else None
     slots = 2048
     stamps = torch.zeros((2, slots, 4), dtype=torch.int64, device=dev)
     eng.clock_stamp(stamps[0].data_ptr(), slots, stream=stream)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()      # (before the probe exists: a device synchronise would wait for it to time out)
+    probe = eng.clock_probe_start() if os.environ.get("R6_PROBE") else None
     j0, t0 = ec.joules(), time.time()
     eng.clock_stamp(stamps[0].data_ptr(), slots, stream=stream)
     e0.record()

@@ -108,15 +108,14 @@ __device__ __forceinline__ void bfly_tw_rot(f2& a, f2& b, const f2 cr)   // a -+
 // 24 operations per row against 12 (three complex multiplies) + 16 for "twiddle,
 // then butterfly"; row 2 has w2 = -i (20 operations).  148 operations per
 // transform instead of 160.
-__device__ __forceinline__ void fft16_fma(f2 (&v)[16])
+// (fft16_fma_rows is that second stage alone: for callers that produce the first stage's outputs themselves)
+__device__ __forceinline__ void fft16_fma_rows(f2 (&v)[16])
 {
     constexpr real C1 = RTLWS_FR_LIT(0.92387953251128675613);    // cos(pi/8)
     constexpr real T1 = -RTLWS_FR_LIT(0.41421356237309504880);   // tan(-pi/8)
     constexpr real H = RTLWS_FR_LIT(0.70710678118654752440);     // cos(pi/4)
     constexpr real C3 = RTLWS_FR_LIT(0.38268343236508977173);    // cos(3 pi/8)
     constexpr real T3 = -RTLWS_FR_LIT(2.41421356237309504880);   // tan(-3 pi/8)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) bfly4(v[m], v[4 + m], v[8 + m], v[12 + m]);
     bfly4(v[0], v[1], v[2], v[3]);                                   // q = 0
     // q = 1: w1 = W16^1 = (C1, T1), w2 = W16^2 = (H, -1)
     bfly_tw(v[4], v[6], mk(H, -RTLWS_FR_LIT(1.0)));
@@ -140,6 +139,13 @@ __device__ __forceinline__ void fft16_fma(f2 (&v)[16])
     bfly_tw(v[12], v[13], mk(C3, T3));
     bfly_tw_rot(v[14], v[15], mk(C3, T3));
     { const f2 x2 = v[13]; v[13] = v[14]; v[14] = x2; }
+}
+
+__device__ __forceinline__ void fft16_fma(f2 (&v)[16])
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bfly4(v[m], v[4 + m], v[8 + m], v[12 + m]);
+    fft16_fma_rows(v);
 }
 
 // (the multiply-then-butterfly form fft16() is the A/B partner: tools/variants/csrc_hooks.patch, -DRTLWS_FFT16_FMA=0)
@@ -214,5 +220,32 @@ __host__ __device__ constexpr real sin16(int r) { return cos16(r + 12); }   // s
 __device__ __forceinline__ real hann_w(int r, const f2 wcs)
 {
     return RTLWS_FR_FMA(-cos16(r), wcs.x, RTLWS_FR_FMA(sin16(r), wcs.y, RTLWS_FR_LIT(0.5)));
+}
+
+// The same window INSIDE the first butterfly layer of a lane's radix-16.  That layer combines the slots
+// m, 4+m, 8+m, 12+m, whose weights are a quarter turn apart: with phi = theta_t + 2 pi m / 16
+//   w = (1 - cos phi, 1 + sin phi, 1 + cos phi, 1 - sin phi) / 2
+// so the layer's first half on the weighted points is, from the UNWEIGHTED sums and differences
+// e0 = x0 + x2, e1 = x0 - x2, o0 = x1 + x3, o1 = x1 - x3 (integers for integer samples),
+//   2 (w0 x0 + w2 x2) = e0 - cos phi e1      2 (w0 x0 - w2 x2) = e1 - cos phi e0
+//   2 (w1 x1 + w3 x3) = o0 + sin phi o1      2 (w1 x1 - w3 x3) = o1 + sin phi o0
+// -- one FMA per component where the unwindowed layer has one addition: the window costs nothing but
+// (cos phi, sin phi) for m < 4, two operations each from the lane's (0.5 cos, 0.5 sin) theta_t.  The factor 2
+// is the caller's (it rides on the pass-1 twiddles).
+__device__ __forceinline__ f2 hann_cs_m(int m, const f2 wcs)         // (cos, sin)(theta_t + 2 pi m / 16)
+{
+    const real c2 = RTLWS_FR_LIT(2.0) * cos16(m), s2 = RTLWS_FR_LIT(2.0) * sin16(m);
+    return mk(RTLWS_FR_FMA(-s2, wcs.y, c2 * wcs.x), RTLWS_FR_FMA(s2, wcs.x, c2 * wcs.y));
+}
+__device__ __forceinline__ void hann_bfly4(f2 e0, f2 e1, f2 o0, f2 o1, const f2 cs, f2& a0, f2& a1, f2& a2, f2& a3)
+{
+    const f2 s0 = mk(RTLWS_FR_FMA(-cs.x, e1.x, e0.x), RTLWS_FR_FMA(-cs.x, e1.y, e0.y));
+    const f2 s1 = mk(RTLWS_FR_FMA(-cs.x, e0.x, e1.x), RTLWS_FR_FMA(-cs.x, e0.y, e1.y));
+    const f2 s2 = mk(RTLWS_FR_FMA(cs.y, o1.x, o0.x), RTLWS_FR_FMA(cs.y, o1.y, o0.y));
+    const f2 s3 = mk(RTLWS_FR_FMA(cs.y, o0.x, o1.x), RTLWS_FR_FMA(cs.y, o0.y, o1.y));
+    a0 = cadd(s0, s2);
+    a2 = csub(s0, s2);
+    a1 = mk(s1.x + s3.y, s1.y - s3.x);   // s1 - i*s3
+    a3 = mk(s1.x - s3.y, s1.y + s3.x);   // s1 + i*s3
 }
 

@@ -108,11 +108,11 @@ constexpr bool f64_fused_kind(int n_fft, int in_kind)
     return (n_fft == 1024 || n_fft == 2048 || n_fft == 4096) && f64_fused_in_kind(in_kind);
 }
 // the last pass's (cos, tan) pairs stay in registers, except in the instantiations whose budget
-// (256 VGPRs at 2 wavefronts per SIMD) they break: those re-read them from the L2-resident 2 KiB
-// table every frame, under the LDS reads
+// (256 VGPRs at 2 wavefronts per SIMD) they break: those re-read them every frame, with the pass-3 LDS
+// reads, from a 2 KiB copy of the table behind the transposition buffer
 constexpr bool f64_fused_tw3_regs(int n_fft, int in_kind, bool win, bool kone)
 {
-    return !(n_fft == 4096 && win && !kone);
+    return !(n_fft == 4096 && win && (!kone || in_kind == IN_CU8));
 }
 // LDS in double2 elements: 16 rows of 17*R3 (the larger of the two transpositions ends at
 // 15*17*R3 + (R3-1)*17 + 16) + one element for the DC slot of the multi-wavefront sizes

@@ -53,6 +53,8 @@
 
 namespace rtlws {
 
+typedef short pk_i16 __attribute__((ext_vector_type(2)));      // (re, im) of one integer point
+
 using namespace f64;      // f2 = double2, real = double, fft16_fma, fft_last, hann_w ... in double
 
 template <int N, int IN, bool WIN, int OUT, bool KONE, bool ROWF32>
@@ -94,31 +96,45 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
         for (int e = threadIdx.x; e < 16 * (R3 / 2); e += T) tw3_lds[e] = p.tw2f[e];
         __syncthreads();
     }
+    // Hann on cmplx_u8 frames lives INSIDE the first butterfly layer of pass 1 (fft_regs_impl.h, hann_bfly4): the
+    // layer's sums and differences are taken on the bytes (packed int16, exact), the weights enter as one FMA
+    // per component where the unwindowed layer has an addition.  Its outputs are twice the windowed layer's:
+    // the pass-1 twiddles carry the 1/2 (exact).
+    constexpr bool HANN_BFLY = WIN && IN == IN_CU8;
+    const double in_scale = HANN_BFLY ? 0.5 * p.in_scale : p.in_scale;
     f2 tw1[16], tw3[R3 / 2];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) tw1[s] = p.tw1f[t * 16 + s];
+    for (int s = 0; s < 16; ++s) {
+        tw1[s] = p.tw1f[t * 16 + s];
+        if constexpr (HANN_BFLY) tw1[s] = mk(0.5 * tw1[s].x, 0.5 * tw1[s].y);
+    }
 #pragma unroll
     for (int m = 0; m < R3 / 2; ++m) tw3[m] = TW3_REGS ? p.tw2f[(t / R3) * (R3 / 2) + m] : mk(0.0, 0.0);
-    // Hann weights from two lane constants (fft_regs_impl.h): sixteen registers pairs for K = 1;
-    // with K-frame accumulators beside them the 256-VGPR budget is 2 short, so that form
-    // regenerates them every frame (two FMAs each)
+    // Hann weights from two lane constants (fft_regs_impl.h): sixteen registers pairs for K = 1 (four (cos, sin)
+    // pairs for cmplx_u8 frames); with K-frame accumulators beside them the 256-VGPR budget is 2 short, so that
+    // form regenerates them every frame (two FMAs each)
     constexpr bool WINREGS = WIN && KONE && N == 1024;
     f2 wcs = WIN ? p.hann_csf[t] : mk(0.0, 0.0);
     double win[16];
+    f2 hcs[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) win[r] = WINREGS ? hann_w(r, wcs) : 1.0;
+    for (int r = 0; r < 16; ++r) win[r] = (WINREGS && !HANN_BFLY) ? hann_w(r, wcs) : 1.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hcs[m] = (WINREGS && HANN_BFLY) ? hann_cs_m(m, wcs) : mk(0.0, 0.0);
 #pragma unroll
     for (int s = 1; s < 16; ++s) asm volatile("" ::"v"(tw1[s].x), "v"(tw1[s].y));
-    if constexpr (WINREGS) {
+    if constexpr (WINREGS && !HANN_BFLY) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(win[r]));
+    }
+    if constexpr (WINREGS && HANN_BFLY) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(hcs[m].x), "v"(hcs[m].y));
     }
     if constexpr (TW3_REGS) {
 #pragma unroll
         for (int m = 0; m < R3 / 2; ++m) asm volatile("" ::"v"(tw3[m].x), "v"(tw3[m].y));
     }
-    const double in_scale = p.in_scale;
-
     const int q1 = t / R3, m2 = t % R3;     // pass 2: (q1, m2); pass 3: (q2, g3) -- the same split
 
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -131,19 +147,32 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             const long frame = g * K + kf;
             f2 v[16];
             if constexpr (WIN && !WINREGS) asm volatile("" : "+v"(wcs.x), "+v"(wcs.y));   // not hoisted
-            if constexpr (IN == IN_CU8) {
+            if constexpr (HANN_BFLY) {
+                // the first butterfly layer of pass 1, on the bytes: (re, im) -> int16 pair by one v_perm_b32,
+                // sums and differences packed (|.| <= 510; the 128 offset cancels in the differences and is
+                // taken off the sums as 256), sign-extended conversions, then the weights (hann_bfly4)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    pk_i16 x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        x[j] = __builtin_bit_cast(pk_i16, __builtin_amdgcn_perm(raw[4 * j + m], raw[4 * j + m], 0x0c010c00u));
+                    const pk_i16 off = {256, 256};
+                    const pk_i16 e0 = x[0] + x[2] - off, e1 = x[0] - x[2], o0 = x[1] + x[3] - off, o1 = x[1] - x[3];
+                    hann_bfly4(mk((double)e0.x, (double)e0.y), mk((double)e1.x, (double)e1.y),
+                               mk((double)o0.x, (double)o0.y), mk((double)o1.x, (double)o1.y),
+                               WINREGS ? hcs[m] : hann_cs_m(m, wcs), v[m], v[4 + m], v[8 + m], v[12 + m]);
+                }
+                long nf = frame + 1;
+                if (kf + 1 == K) nf = (g + gridDim.x) * K;
+                if (nf >= ngroups * K) nf = frame;        // in bounds, result unused
+                load_raw(nf);
+            } else if constexpr (IN == IN_CU8) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    // (double)u8 is exact; the 128 offset is kept on the rectangular path (it only
-                    // reaches bin 0, which is never output: src/spectrum.c:31) and folded into one
-                    // FMA on the windowed one ((x - 128) * w, -128 * w exact)
-                    const double re = (double)(raw[r] & 0xffu), im = (double)((raw[r] >> 8) & 0xffu);
-                    if constexpr (WIN) {
-                        const double w = WINREGS ? win[r] : hann_w(r, wcs), c = -128.0 * w;
-                        v[r] = mk(fma(re, w, c), fma(im, w, c));
-                    } else {
-                        v[r] = mk(re, im);
-                    }
+                    // (double)u8 is exact; the 128 offset is kept (it only reaches bin 0, which is never
+                    // output: src/spectrum.c:31)
+                    v[r] = mk((double)(raw[r] & 0xffu), (double)((raw[r] >> 8) & 0xffu));
                 }
                 long nf = frame + 1;
                 if (kf + 1 == K) nf = (g + gridDim.x) * K;
@@ -163,7 +192,8 @@ __global__ __launch_bounds__(N / 16, 2) void spectra_f64_fused(const SpectraPara
             }
 
             // ---- pass 1: radix-16 over the slow digit, twiddle W_N^(m1*q1) (carries the 1/128)
-            fft16_sel(v);
+            if constexpr (HANN_BFLY) fft16_fma_rows(v);
+            else fft16_sel(v);
             v[0] = mk(v[0].x * in_scale, v[0].y * in_scale);
 #pragma unroll
             for (int s = 1; s < 16; ++s) v[s] = cmul(v[s], tw1[s]);

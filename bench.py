@@ -202,6 +202,11 @@ def device_for_rank(local_rank, device_count):
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     if rehearsal():
         return local_rank % device_count
+    # a launcher may show every rank ONE device of its own through a visibility mask: that device is index 0 in
+    # every rank (rank 0 still checks, by PCI bus id, that no two ranks ended up on the same one)
+    mask = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+    if device_count == 1 and local_rank > 0 and mask and "," not in mask:
+        return 0
     if not 0 <= local_rank < device_count:
         raise SystemExit("bench.py: LOCAL_RANK %d but this host has %d HIP device(s)" % (local_rank, device_count))
     return local_rank
@@ -971,17 +976,21 @@ def placement_record(rank, local_rank, topo, **figures):
     rec = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(),
            "device": local_rank if topo is None else topo.get("device", local_rank),
            "bus_id": (topo or {}).get("bus_id", ""), "numa_node": (topo or {}).get("numa_node", -1),
-           "cpus_pinned": (topo or {}).get("cpus_pinned", 0)}
+           "cpus_pinned": (topo or {}).get("cpus_pinned", 0),
+           # a launcher may give every rank ONE visible device (then every rank says "device 0"): the mask tells
+           # such ranks apart where the bus id is unknown
+           "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""}
     rec.update(figures)
     return rec
 
 
 def check_distinct_devices(records, allow_shared=False):
-    """One process per GPU: no two ranks of a host on one device (bus id where known, else host + device index).
-    Returns the list of clashes; rank 0 refuses to print an N-GPU line over them unless `allow_shared` (rehearsal)."""
+    """One process per GPU: no two ranks of a host on one device (bus id where known, else host + device index
+    under the rank's visibility mask).  Returns the list of clashes; rank 0 refuses to print an N-GPU line over them
+    unless `allow_shared` (rehearsal)."""
     seen, clashes = {}, []
     for r in records:
-        key = (r["host"], r["bus_id"] or "device %d" % r["device"])
+        key = (r["host"], r["bus_id"] or "device %d of [%s]" % (r["device"], r.get("visible_devices", "")))
         if key in seen:
             clashes.append({"ranks": [seen[key], r["rank"]], "host": key[0], "device": key[1]})
         seen.setdefault(key, r["rank"])

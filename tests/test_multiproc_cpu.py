@@ -136,6 +136,10 @@ def test_distinct_device_check_is_pure():
     assert bad == [{"ranks": [3, 8], "host": "n0", "device": eight[3]["bus_id"]}]
     assert bench.check_distinct_devices([rec(0, "n0", "", 0), rec(1, "n0", "", 0)]) != []          # no bus id: by index
     assert bench.check_distinct_devices([rec(0, "n0", "", 0), rec(1, "n0", "", 0)], allow_shared=True) == []
+    # a launcher that shows every rank ONE device: all say "device 0", their visibility masks tell them apart
+    masked = [dict(rec(r, "n0", "", 0), visible_devices=str(r)) for r in range(8)]
+    assert bench.check_distinct_devices(masked) == []
+    assert bench.check_distinct_devices(masked + [dict(rec(8, "n0", "", 0), visible_devices="3")]) != []
 
 
 def test_bench_gpus_n_without_the_devices_fails_loudly():
@@ -161,7 +165,7 @@ def test_fan_out_decision():
     assert not bench.needs_fan_out(2, {"WORLD_SIZE": "2", "RANK": "0"})     # already a rank
 
 
-def test_rank_and_stream_placement_for_1_2_8_devices():
+def test_rank_and_stream_placement_for_1_2_8_devices(monkeypatch):
     """VERDICT r2 "next" #5: the rank -> device and stream -> device rules as functions, checked
     for device counts this container cannot have.  bench.py's rule and the C driver's
     (rtlws_stream_device_for, include/rtlws_stream.h; rtlws_multi_stream --plan-only) must agree."""
@@ -174,6 +178,8 @@ def test_rank_and_stream_placement_for_1_2_8_devices():
     L.rtlws_stream_device_for.argtypes = [ctypes.c_int, ctypes.c_int]
     L.rtlws_stream_device_for.restype = ctypes.c_int
     exe = os.path.join(rtlws.LIB_DIR, "rtlws_multi_stream")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
     for n in (1, 2, 8):
         plan = bench.multi_stream_plan(8, n)
         assert plan == [i % n for i in range(8)]
@@ -183,6 +189,13 @@ def test_rank_and_stream_placement_for_1_2_8_devices():
         assert [bench.device_for_rank(r, n) for r in range(n)] == list(range(n))      # one rank, one device
         with pytest.raises(SystemExit):
             bench.device_for_rank(n, n)                                              # no silent sharing
+    # ... except where a launcher shows every rank one device of its own through a visibility mask
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")
+    assert bench.device_for_rank(5, 1) == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    with pytest.raises(SystemExit):
+        bench.device_for_rank(5, 1)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert bench.multi_stream_plan(8, 8) == list(range(8))                           # configs[4]: GPU g <- stream g
     assert L.rtlws_stream_device_for(3, 0) == -1 and L.rtlws_stream_device_for(-1, 8) == -1
     with pytest.raises(SystemExit):
